@@ -1,0 +1,180 @@
+"""Generate golden vectors by importing the reference's own modules (this container only).
+
+Run:  python tests/golden/make_golden.py     (needs /root/reference; writes tests/golden/*.npz)
+
+The reference's cnn.py imports unmodified.  gru.py / vqa_model.py / dataset.py import `torchtext` and
+`torchvision`, which are not installed here; two tiny in-memory modules are registered in sys.modules before
+the import.  They only cover vocabulary construction (host strings) and RandomHorizontalFlip
+— none of the hot-path arithmetic: conv, BN, GRU, Linear, weight_norm, softmax and BCE all execute in the
+real torch as called by the reference's own code.
+
+Inputs and weights come from vqa_amd.synth (a deterministic integer hash), so only OUTPUTS are stored.
+"""
+import json
+import os
+import pickle
+import sys
+import tempfile
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from vqa_amd import synth  # noqa: E402
+
+warnings.filterwarnings('ignore')
+sys.dont_write_bytecode = True
+
+# name, hidden, classes, padding, pooling, batch, image size, tokens
+CONFIGS = [
+    ('h1024_p2_max', 1024, 3129, 2, 'max', 4, 224, 14),
+    ('h512_p0_avg', 512, 3129, 0, 'avg', 2, 224, 14),
+    ('h64_p5_max', 64, 50, 5, 'max', 3, 224, 9),
+    ('h128_p2_max_448', 128, 50, 2, 'max', 2, 448, 30),
+]
+SEED_W, SEED_X = 42, 1234
+SAMPLE = 2048
+
+
+def install_standins():
+    tt, ttv = types.ModuleType('torchtext'), types.ModuleType('torchtext.vocab')
+
+    class Vocab:  # legacy torchtext.vocab.Vocab semantics used at reference gru.py:39-44
+        def __init__(self, counter, vectors=None, min_freq=1, specials=()):
+            self.itos = list(specials)
+            words = sorted(counter.items(), key=lambda t: t[0])
+            words.sort(key=lambda t: t[1], reverse=True)
+            self.itos += [w for w, c in words if c >= min_freq and w not in specials]
+            self.stoi = {w: i for i, w in enumerate(self.itos)}
+            self.vectors = None
+
+        def set_vectors(self, stoi, vectors, dim):
+            self.vectors = vectors
+
+    ttv.Vocab = Vocab
+    tt.vocab = ttv
+    tv, tvt = types.ModuleType('torchvision'), types.ModuleType('torchvision.transforms')
+    tvf = types.ModuleType('torchvision.transforms.functional')
+
+    class RandomHorizontalFlip(torch.nn.Module):
+        def __init__(self, p=0.5):
+            super().__init__()
+            self.p = p
+
+        def forward(self, img):
+            return img.flip(-1) if torch.rand(1) < self.p else img
+
+    tvt.RandomHorizontalFlip, tvt.functional, tv.transforms = RandomHorizontalFlip, tvf, tvt
+    for name, mod in [('torchtext', tt), ('torchtext.vocab', ttv), ('torchvision', tv),
+                      ('torchvision.transforms', tvt), ('torchvision.transforms.functional', tvf)]:
+        sys.modules[name] = mod
+
+
+def sample_idx(n):
+    """Deterministic sample positions inside a flat tensor of n elements (shared with the tests)."""
+    if n <= SAMPLE:
+        return np.arange(n)
+    return (np.arange(SAMPLE, dtype=np.int64) * 2654435761 + 12345) % n
+
+
+def fixture_files(tmp, vocab_words=40):
+    """Tiny digit-free question file (reference gru.py:65 turns digits into <number>) + label2ans pickle."""
+    alphabet = 'abcdefghijklmnopqrstuvwxyz'
+    words = [alphabet[i % 26] + alphabet[(i // 26) % 26] + 'x' for i in range(vocab_words)]
+    qs = [{'question': ' '.join(words[(3 * i + j) % vocab_words] for j in range(6))} for i in range(2 * vocab_words)]
+    qpath = os.path.join(tmp, 'questions.json')
+    json.dump({'questions': qs}, open(qpath, 'w'))
+    return qpath
+
+
+def run_config(vqa_model, name, hidden, classes, padding, pooling, batch, size, tokens, tmp):
+    qpath = fixture_files(tmp)
+    lpath = os.path.join(tmp, f'label2ans_{classes}.pkl')
+    pickle.dump([f'ans{i}' for i in range(classes)], open(lpath, 'wb'))
+    model = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': hidden, 'n_layers': 1,
+                           'train_question_path': qpath}, lpath, 256, padding, 0.0, pooling, 'relu')
+    vocab = len(model.gru.word_idx_mappings)
+    sd = synth.state_dict(SEED_W, hidden, classes, vocab)
+    model.load_state_dict(sd, strict=True)
+    img = synth.images(SEED_X, batch, size)                  # fp16 like dataset.py:98
+    q = synth.questions(SEED_X, batch, tokens, vocab)
+    tgt = synth.targets(SEED_X, batch, classes)
+    crit = torch.nn.BCEWithLogitsLoss(reduction='sum')
+    out = {'vocab': np.int64(vocab)}
+
+    # ---- eval forward (running stats from the synthetic state) + soft accuracy (vqa_model.py:127-130)
+    model.eval()
+    with torch.no_grad():
+        lo = model(img.float(), q)
+        out['eval_logits'] = lo.numpy()
+        out['eval_loss'] = np.float64(crit(lo, tgt))
+        pred = torch.argmax(lo, dim=1)
+        out['eval_acc_sum'] = np.float64(sum(float(tgt[i][int(p)]) for i, p in enumerate(pred)))
+        if classes <= 50 and size == 224:                    # a larger fixed eval set for the accuracy check
+            img2, q2 = synth.images(SEED_X + 1, 32, size), synth.questions(SEED_X + 1, 32, tokens, vocab)
+            tgt2 = synth.targets(SEED_X + 1, 32, classes)
+            lo2 = model(img2.float(), q2)
+            pred2 = torch.argmax(lo2, dim=1)
+            out['eval32_logits'] = lo2.numpy()
+            out['eval32_acc_sum'] = np.float64(sum(float(tgt2[i][int(p)]) for i, p in enumerate(pred2)))
+            print('  eval32 acc sum', out['eval32_acc_sum'])
+
+    # ---- train step: fwd, loss, bwd (vqa_model.py:254-256)
+    model.train()
+    opt = torch.optim.Adamax(model.parameters(), lr=2e-3)
+    opt.zero_grad()
+    cnn_out = model.cnn(img.float())
+    gru_out = model.gru(q)
+    out['cnn_out'], out['gru_out'] = cnn_out.detach().numpy(), gru_out.detach().numpy()
+    for m in model.cnn.modules():                            # undo the extra running-stat update above
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(sd_lookup(sd, model, m, 'running_mean'))
+            m.running_var.copy_(sd_lookup(sd, model, m, 'running_var'))
+            m.num_batches_tracked.zero_()
+    logits = model(img.float(), q)
+    loss = crit(logits, tgt)
+    loss.backward()
+    out['logits'], out['loss'] = logits.detach().numpy(), np.float64(loss)
+    for n, p in model.named_parameters():
+        g = p.grad.detach().reshape(-1)
+        out[f'gnorm/{n}'] = np.float64(g.double().norm())
+        out[f'gsamp/{n}'] = g.numpy()[sample_idx(g.numel())]
+    for n, b in model.named_buffers():
+        if 'running' in n:
+            out[f'stat/{n}'] = b.detach().numpy().copy()
+
+    # ---- clip + Adamax (vqa_model.py:259, :266)
+    total = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=0.25, norm_type=2)
+    out['total_norm'] = np.float64(total)
+    opt.step()
+    for n, p in model.named_parameters():
+        f = p.detach().reshape(-1)
+        out[f'pnorm/{n}'] = np.float64(f.double().norm())
+        out[f'psamp/{n}'] = f.numpy()[sample_idx(f.numel())]
+    np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+    print(f'{name}: loss={float(loss):.6f} total_norm={float(total):.6f} vocab={vocab} '
+          f'eval_acc_sum={out["eval_acc_sum"]}')
+
+
+def sd_lookup(sd, model, module, field):
+    for n, m in model.named_modules():
+        if m is module:
+            return sd[f'{n}.{field}']
+    raise KeyError
+
+
+def main():
+    install_standins()
+    sys.path.insert(0, '/root/reference')
+    import vqa_model  # the reference's module
+    torch.manual_seed(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        for cfg in CONFIGS:
+            run_config(vqa_model, *cfg, tmp)
+
+
+if __name__ == '__main__':
+    main()

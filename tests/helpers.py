@@ -1,0 +1,43 @@
+"""Shared helpers for the parity tests: golden loading and the synthetic cases they were made from."""
+import os
+
+import numpy as np
+import torch
+
+from vqa_amd import synth
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+SEED_W, SEED_X, SAMPLE = 42, 1234, 2048
+
+# name -> hidden, classes, padding, pooling, batch, image size, tokens   (tests/golden/make_golden.py CONFIGS)
+CONFIGS = {
+    'h1024_p2_max': (1024, 3129, 2, 'max', 4, 224, 14),
+    'h512_p0_avg': (512, 3129, 0, 'avg', 2, 224, 14),
+    'h64_p5_max': (64, 50, 5, 'max', 3, 224, 9),
+    'h128_p2_max_448': (128, 50, 2, 'max', 2, 448, 30),
+}
+
+
+def sample_idx(n):
+    if n <= SAMPLE:
+        return np.arange(n)
+    return (np.arange(SAMPLE, dtype=np.int64) * 2654435761 + 12345) % n
+
+
+def load_case(name):
+    hidden, classes, padding, pooling, batch, size, tokens = CONFIGS[name]
+    g = np.load(os.path.join(GOLDEN_DIR, f'{name}.npz'))
+    vocab = int(g['vocab'])
+    case = dict(hidden=hidden, classes=classes, padding=padding, pooling=pooling, batch=batch, size=size,
+                tokens=tokens, vocab=vocab, golden=g,
+                sd=synth.state_dict(SEED_W, hidden, classes, vocab),
+                images=synth.images(SEED_X, batch, size),
+                questions=synth.questions(SEED_X, batch, tokens, vocab),
+                targets=synth.targets(SEED_X, batch, classes))
+    return case
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(np.asarray(a), dtype=torch.float64).reshape(-1)
+    b = torch.as_tensor(np.asarray(b), dtype=torch.float64).reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))

@@ -54,7 +54,8 @@ def test_oracle_matches_reference(name, monkeypatch):
     for k, p in new.items():   # Adamax's first step moves every weight by lr*sign(g): insensitive to the above
         if k.startswith('cnn.convolutions') and k.endswith('.bias') and int(k.split('.')[2]) in O.CONV_IDX:
             continue           # ... except conv biases, whose gradient is pure rounding noise (sign is arbitrary)
-        assert rel_err(p.reshape(-1).numpy()[sample_idx(p.numel())], g[f'psamp/{k}']) < 2e-3, k
+        d = np.abs(p.reshape(-1).numpy()[sample_idx(p.numel())] - g[f'psamp/{k}'])
+        assert (d > 1e-5).mean() <= 0.01, k   # a near-zero gradient whose sign differs moves a weight by 2*lr
 
 
 def test_accurate_norm_is_closer_to_fp64():

@@ -1,0 +1,69 @@
+"""GPU: MFMA GEMM (vqa_gemm) and layout probes against plain PyTorch fp32 references, through the C-ABI."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(A, B, trans, out_dtype=torch.float32, bias=None, rowadd=None, group=1, act=0, acc=None):
+    from vqa_amd import _lib as L
+    if trans:
+        K, M = A.shape
+        N = B.shape[1]
+    else:
+        M, K = A.shape
+        N = B.shape[0]
+    C = acc.clone() if acc is not None else torch.empty(M, N, device='cuda', dtype=out_dtype)
+    L.call('vqa_gemm', L.dt(A), int(trans), M, N, K, A, A.stride(0), B, B.stride(0), C, C.stride(0), L.dt(C),
+           bias, rowadd, group, act, int(acc is not None), None, 0)
+    return C
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-6), (torch.bfloat16, 2e-6)])
+@pytest.mark.parametrize('trans', [0, 1])
+@pytest.mark.parametrize('M,N,K', [(64, 64, 32), (256, 3129, 1024), (100, 52, 300 + 4), (3584, 3072, 320),
+                                   (17, 1, 64)])
+def test_gemm(dtype, tol, trans, M, N, K):
+    torch.manual_seed(0)
+    # exact-in-bf16 integer-ish data so the bf16 path is compared without input rounding
+    A = (torch.randint(-8, 9, (M, K), device='cuda').float() / 8).to(dtype)
+    B = (torch.randint(-8, 9, (N, K), device='cuda').float() / 8).to(dtype)
+    ref = A.double() @ B.double().t()
+    if trans:
+        Ain, Bin = A.t().contiguous(), B.t().contiguous()
+        if (M % 8) or (N % 8):        # TN vector loads need aligned rows: pad the leading dimension
+            Ap = torch.zeros(K, (M + 7) // 8 * 8, device='cuda', dtype=dtype); Ap[:, :M] = Ain; Ain = Ap[:, :M]
+            Bp = torch.zeros(K, (N + 7) // 8 * 8, device='cuda', dtype=dtype); Bp[:, :N] = Bin; Bin = Bp[:, :N]
+    else:
+        Ain, Bin = A, B
+    C = _gemm(Ain, Bin, trans)
+    err = (C.double() - ref).norm() / ref.norm()
+    assert float(err) < tol
+
+
+def test_gemm_epilogue():
+    torch.manual_seed(1)
+    M, N, K, G = 50, 72, 64, 25
+    A = torch.randn(M, K, device='cuda')
+    B = torch.randn(N, K, device='cuda')
+    bias = torch.randn(N, device='cuda')
+    rowadd = torch.randn(M // G, N, device='cuda')
+    acc = torch.randn(M, N, device='cuda')
+    ref = torch.relu(A @ B.t() + bias + rowadd.repeat_interleave(G, 0)) + acc
+    C = _gemm(A, B, 0, bias=bias, rowadd=rowadd, group=G, act=1, acc=acc)
+    assert float((C - ref).norm() / ref.norm()) < 1e-5
+    Cb = _gemm(A.bfloat16(), B.bfloat16(), 0, out_dtype=torch.bfloat16)
+    refb = A.bfloat16().float() @ B.bfloat16().float().t()
+    assert float((Cb.float() - refb).norm() / refb.norm()) < 5e-3
+
+
+def test_probe_tr16():
+    """ds_read_b64_tr_b16: lane i of 16-lane group g receives column i of rows 4g..4g+3 (element q = row 4g+q)."""
+    from vqa_amd import _lib as L
+    tile = torch.arange(256, device='cuda', dtype=torch.float32).reshape(16, 16)   # value = 16*row + col
+    out = torch.empty(64, 4, device='cuda')
+    L.call('vqa_probe_tr16', tile.bfloat16(), out)
+    lane = torch.arange(64, device='cuda')
+    g, i = lane // 16, lane % 16
+    exp = torch.stack([(4 * g + q) * 16 + i for q in range(4)], dim=1).float()
+    assert torch.equal(out, exp), out

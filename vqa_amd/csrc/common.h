@@ -1,0 +1,83 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the VQA hot path.
+// Wave = 64 lanes.  MFMA shapes used everywhere: v_mfma_f32_16x16x32_bf16 (bf16 in, f32 accumulate) and
+// v_mfma_f32_16x16x4_f32 (exact f32).  Both share one C/D layout: col = lane & 15, row = 4*(lane>>4) + reg.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+#define VQA_OK 0
+#define VQA_ERR_ARG 1
+#define VQA_ERR_LAUNCH 2
+
+#define VQA_F32 0
+#define VQA_BF16 1
+#define VQA_F16 2
+
+#define CHECK_LAUNCH()                                         \
+    do {                                                       \
+        hipError_t e_ = hipGetLastError();                     \
+        if (e_ != hipSuccess) return VQA_ERR_LAUNCH;           \
+    } while (0)
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+__device__ __forceinline__ float to_f32(_Float16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
+
+// One "K-chunk" = 16 bytes per lane of each operand.  For bf16 that is 8 k-values per lane and ONE
+// 16x16x32 MFMA (lane group g = lane>>4 holds k = 8g..8g+7).  For f32 it is 4 k-values per lane and FOUR
+// 16x16x4 MFMAs (MFMA j takes element j of every lane: k = 4g + j).  Either way a chunk covers
+// KCHUNK = 4 * VEC consecutive k of a row whose lane group g reads bytes [16g, 16g+16).
+// `rows` feeds the MFMA A operand (D rows), `cols` the B operand (D columns).
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+    static constexpr int VEC = 4;
+    static __device__ __forceinline__ void mma(f32x4& c, const uint4& rows, const uint4& cols) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(rows.x), __uint_as_float(cols.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(rows.y), __uint_as_float(cols.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(rows.z), __uint_as_float(cols.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(rows.w), __uint_as_float(cols.w), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16> {
+    static constexpr int VEC = 8;
+    static __device__ __forceinline__ void mma(f32x4& c, const uint4& rows, const uint4& cols) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, rows),
+                                                    __builtin_bit_cast(bf16x8, cols), c, 0, 0, 0);
+    }
+};
+
+// Sum over the 16 lanes that share lane>>4 (the lanes holding different D columns of the same rows).
+__device__ __forceinline__ float sum16(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = sum16(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ void store_vec4(T* p, const float* v);
+template <> __device__ __forceinline__ void store_vec4<float>(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store_vec4<bf16>(bf16* p, const float* v) {
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = o;
+}

@@ -1,0 +1,162 @@
+// LDS-tiled MFMA GEMM for the GRU / fusion-head / classifier layers.
+//   NT:  C[M,N] = A[M,K] * B[N,K]^T      (forward linears:  x * W^T;  input grads with a pre-transposed W)
+//   TN:  C[M,N] = A[K,M]^T * B[K,N]      (weight grads:  dY^T * X, reduction over the batch dimension)
+// Epilogue (fused): + bias[n], + rowadd[m / group][n], ReLU, accumulate into C, optional second bf16 copy.
+// 64x64 tile, 4 waves (2x2), each wave 2x2 MFMA tiles; operands staged through LDS k-contiguous so that both
+// modes feed the MFMA with one ds_read_b128 per lane per fragment.  The MFMA's D rows are the N index, so a lane
+// owns 4 consecutive n of one m: 16-byte stores.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64;
+constexpr int ROWB = 80;  // LDS row: 64 bytes of k + 16 pad (bank spread for ds_read_b128)
+
+struct GemmArgs {
+    int M, N, K;
+    const void* A; int lda;
+    const void* B; int ldb;
+    void* C; int ldc;
+    const float* bias;
+    const float* rowadd; int rowadd_group;
+    int act, accumulate;
+    bf16* C2; int ldc2;
+};
+
+template <typename T>
+__device__ __forceinline__ uint4 load_row_chunk(const T* base, long row, int ld, int k, int K, bool row_ok) {
+    // 16 bytes of k starting at k (k-contiguous source); zero outside the matrix.
+    constexpr int VEC = Mma<T>::VEC;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (!row_ok) return v;
+    const T* p = base + row * ld + k;
+    if (k + VEC <= K && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+        v = *reinterpret_cast<const uint4*>(p);
+    } else {
+        T tmp[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) tmp[j] = (k + j < K) ? p[j] : from_f32<T>(0.f);
+        v = *reinterpret_cast<uint4*>(tmp);
+    }
+    return v;
+}
+
+template <typename T, typename TC, bool TN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    constexpr int VEC = Mma<T>::VEC;
+    constexpr int KC = 4 * VEC;  // k per stage
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 64 * ROWB];
+    unsigned char* As = lds;
+    unsigned char* Bs = lds + 64 * ROWB;
+    const T* A = static_cast<const T*>(g.A);
+    const T* B = static_cast<const T*>(g.B);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int r = lane & 15, q = lane >> 4;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < g.K; k0 += KC) {
+        if (!TN) {
+            const int row = tid >> 2, vc = tid & 3;
+            uint4 va = load_row_chunk<T>(A, m0 + row, g.lda, k0 + vc * VEC, g.K, m0 + row < g.M);
+            uint4 vb = load_row_chunk<T>(B, n0 + row, g.ldb, k0 + vc * VEC, g.K, n0 + row < g.N);
+            *reinterpret_cast<uint4*>(As + row * ROWB + vc * 16) = va;
+            *reinterpret_cast<uint4*>(Bs + row * ROWB + vc * 16) = vb;
+        } else {
+            // source rows are k, contiguous along m / n: load 16 B along m, scatter transposed into LDS
+            constexpr int VPR = 64 / VEC;  // vectors per k-row of the tile
+            const int kk = tid / VPR, mv = tid % VPR;
+            const bool k_ok = k0 + kk < g.K;
+            uint4 va = load_row_chunk<T>(A, k0 + kk, g.lda, m0 + mv * VEC, g.M, k_ok);
+            uint4 vb = load_row_chunk<T>(B, k0 + kk, g.ldb, n0 + mv * VEC, g.N, k_ok);
+            const T* ea = reinterpret_cast<const T*>(&va);
+            const T* eb = reinterpret_cast<const T*>(&vb);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                *reinterpret_cast<T*>(As + (mv * VEC + j) * ROWB + kk * sizeof(T)) = ea[j];
+                *reinterpret_cast<T*>(Bs + (mv * VEC + j) * ROWB + kk * sizeof(T)) = eb[j];
+            }
+        }
+        __syncthreads();
+        uint4 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[i] = *reinterpret_cast<const uint4*>(As + (wm * 32 + i * 16 + r) * ROWB + q * 16);
+            fb[i] = *reinterpret_cast<const uint4*>(Bs + (wn * 32 + i * 16 + r) * ROWB + q * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) Mma<T>::mma(acc[i][j], fb[j], fa[i]);  // D rows = n, D cols = m
+        __syncthreads();
+    }
+
+    TC* C = static_cast<TC*>(g.C);
+    const bool vec_ok = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                        (g.C2 == nullptr || g.ldc2 % 4 == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 32 + i * 16 + r;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 32 + j * 16 + q * 4;
+            if (n >= g.N) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[i][j][e];
+                const int ne = n + e;
+                if (ne < g.N) {
+                    if (g.bias) x += g.bias[ne];
+                    if (g.rowadd) x += g.rowadd[(long)(m / g.rowadd_group) * g.N + ne];
+                    if (g.act == 1) x = fmaxf(x, 0.f);
+                    if (g.accumulate) x += to_f32(C[(long)m * g.ldc + ne]);
+                }
+                v[e] = x;
+            }
+            if (vec_ok && n + 3 < g.N) {
+                store_vec4<TC>(C + (long)m * g.ldc + n, v);
+                if (g.C2) store_vec4<bf16>(g.C2 + (long)m * g.ldc2 + n, v);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < g.N) {
+                        C[(long)m * g.ldc + n + e] = from_f32<TC>(v[e]);
+                        if (g.C2) g.C2[(long)m * g.ldc2 + n + e] = (bf16)v[e];
+                    }
+            }
+        }
+    }
+}
+
+template <typename T, typename TC>
+int launch(hipStream_t s, int trans, const GemmArgs& g) {
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
+    if (trans) hipLaunchKernelGGL((gemm_kernel<T, TC, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<T, TC, false>), grid, dim3(256), 0, s, g);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+}  // namespace
+
+extern "C" int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K, const void* A, int lda,
+                        const void* B, int ldb, void* C, int ldc, int c_dtype, const float* bias,
+                        const float* rowadd, int rowadd_group, int act, int accumulate, void* C2, int ldc2) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return VQA_ERR_ARG;
+    if (rowadd && rowadd_group <= 0) return VQA_ERR_ARG;
+    GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, bias, rowadd, rowadd_group, act, accumulate,
+               static_cast<bf16*>(C2), ldc2};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == VQA_F32 && c_dtype == VQA_F32) return launch<float, float>(s, trans, g);
+    if (dtype == VQA_BF16 && c_dtype == VQA_F32) return launch<bf16, float>(s, trans, g);
+    if (dtype == VQA_BF16 && c_dtype == VQA_BF16) return launch<bf16, bf16>(s, trans, g);
+    return VQA_ERR_ARG;
+}

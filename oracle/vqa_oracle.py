@@ -49,6 +49,25 @@ def weight_norm_w(g, v):
     return v * (g / nrm)
 
 
+class _Round(torch.autograd.Function):
+    """Storage-precision emulation for the bf16 path: round the value on the way forward (`fwd`) and / or the
+    gradient on the way back (`bwd`) to `dtype`, all arithmetic staying fp32.  With dtype=None it is the identity.
+    Used only to compare the bf16 HIP kernels against the same algorithm with the same rounding points."""
+
+    @staticmethod
+    def forward(ctx, t, dtype, fwd, bwd):
+        ctx.dtype, ctx.bwd = dtype, bwd
+        return t.to(dtype).to(t.dtype) if fwd else t.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(ctx.dtype).to(g.dtype) if ctx.bwd else g), None, None, None
+
+
+def _q(t, dtype, fwd=True, bwd=False):
+    return t if dtype is None else _Round.apply(t, dtype, fwd, bwd)
+
+
 class _BatchNormTrain(torch.autograd.Function):
     """Training-mode BatchNorm2d with the closed-form backward
         dy = (gamma * invstd) * (dz - mean(dz) - xhat * mean(dz * xhat)),  dgamma = sum(dz*xhat),  dbeta = sum(dz)
@@ -76,15 +95,20 @@ class _BatchNormTrain(torch.autograd.Function):
         return dy, dgamma, dbeta
 
 
-def cnn_forward(sd, x, padding=2, pooling='max', training=True, new_stats=None, inter=None):
+def cnn_forward(sd, x, padding=2, pooling='max', training=True, new_stats=None, inter=None, act_dtype=None):
     """reference cnn.py:49-54.  x [B,3,S,S] fp32 -> [B,k,256].
+
+    act_dtype=torch.bfloat16 emulates the bf16 path's storage rounding (image, conv weights, conv output y,
+    activation a, and the gradients dy / da) with fp32 arithmetic in between; None is the plain fp32 algorithm.
 
     Training mode: batch statistics, biased variance for the normalisation, unbiased for the running
     update (written to `new_stats` if given); eval mode: running statistics."""
+    x = _q(x, act_dtype)
     for li, ci in enumerate(CONV_IDX):
         w, b = sd[f'cnn.convolutions.{ci}.weight'], sd[f'cnn.convolutions.{ci}.bias']
         gamma, beta = sd[f'cnn.convolutions.{ci + 1}.weight'], sd[f'cnn.convolutions.{ci + 1}.bias']
-        y = F.conv2d(x, w, b, padding=padding if li in PAD_LAYERS else 0)
+        y = F.conv2d(x, _q(w, act_dtype), b, padding=padding if li in PAD_LAYERS else 0)
+        y = _q(y, act_dtype, True, True)
         if training:
             z, mean, var = _BatchNormTrain.apply(y, gamma, beta)
             if new_stats is not None:
@@ -101,6 +125,7 @@ def cnn_forward(sd, x, padding=2, pooling='max', training=True, new_stats=None, 
         x = torch.relu(z)
         if li in POOL_AFTER:
             x = F.max_pool2d(x, 2, 2) if pooling == 'max' else F.avg_pool2d(x, 2, 2)
+        x = _q(x, act_dtype, True, True)
         if inter is not None:
             inter[f'cnn.act{li}'] = x
     x = x.permute(0, 2, 3, 1)

@@ -1,0 +1,193 @@
+"""GPU: conv / BN / pool HIP kernels and the whole encoder against PyTorch-CPU fp32 references (the oracle)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {'fp32': torch.float32, 'bf16': torch.bfloat16}
+
+
+def _ints(shape, lo=-4, hi=5, scale=1.0):
+    return torch.randint(lo, hi, shape).float() * scale
+
+
+def _nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('B,cin,cout,H,W,pad', [(2, 16, 16, 20, 20, 0), (3, 16, 32, 13, 17, 2), (2, 32, 64, 9, 9, 2),
+                                                (1, 64, 64, 30, 30, 0), (2, 128, 256, 14, 14, 0),
+                                                (2, 256, 256, 12, 12, 0), (1, 16, 16, 70, 226, 2)])
+def test_conv_fwd_dgrad_wgrad_exact(prec, B, cin, cout, H, W, pad):
+    """Small-integer data: every product and sum is exact in bf16/f32, so results must match bit for bit."""
+    from vqa_amd import cnn as C
+    torch.manual_seed(B * 1000 + cin + cout + H)
+    dt = DT[prec]
+    x = _ints((B, cin, H, W), -2, 3)
+    w = _ints((cout, cin, 3, 3), -2, 3)
+    bias = _ints((cout,), -3, 4)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, bias, padding=pad)
+    dy = _ints(tuple(y_ref.shape), -2, 3)
+    y_ref.backward(dy)
+
+    xd = _nhwc(x, dt)
+    wpk = C.pack_weights(w.cuda(), cin, dt, dgrad=False)
+    y, stats = C.conv_fwd(xd, wpk, bias.cuda(), cout, pad, True)
+    y_st = y_ref.detach().to(dt).float()          # what a bf16 store keeps (sums above 256 round)
+    assert torch.equal(y.float().cpu().permute(0, 3, 1, 2), y_st)
+    s = stats.sum(0).cpu()
+    assert torch.allclose(s[:, 0], y_st.sum((0, 2, 3)), rtol=1e-5)
+    assert torch.allclose(s[:, 1], (y_st ** 2).sum((0, 2, 3)), rtol=1e-5)
+
+    dyd = _nhwc(dy, dt)
+    wpk_d = C.pack_weights(w.cuda(), cin, dt, dgrad=True)
+    dx, _ = C.conv_fwd(dyd, wpk_d, None, cin, 2 - pad, False)
+    assert torch.equal(dx.float().cpu().permute(0, 3, 1, 2), xr.grad.to(dt).float())
+
+    dw = C.conv_wgrad(xd, dyd, cin, pad)
+    assert torch.equal(dw.cpu(), wr.grad)
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', 1e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('pool', [0, 1, 2])
+@pytest.mark.parametrize('C', [16, 64, 256])
+def test_bn_relu_pool_fwd_bwd(prec, tol, pool, C):
+    from vqa_amd import _lib as L, cnn as M
+    from oracle import vqa_oracle as O
+    import ctypes
+    torch.manual_seed(C + pool)
+    dt = DT[prec]
+    B, H, W = 3, 10, 12
+    y = (torch.randn(B, C, H, W) * 1.5 + 0.3).to(dt).float()
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.3
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z, mean, var = O._BatchNormTrain.apply(yr, gr, br)
+    a_ref = torch.relu(z)
+    if pool == 1:
+        a_ref = F.max_pool2d(a_ref, 2, 2)
+    elif pool == 2:
+        a_ref = F.avg_pool2d(a_ref, 2, 2)
+    da = torch.randn_like(a_ref).to(dt).float()
+    a_ref.backward(da)
+
+    yd = _nhwc(y, dt)
+    # statistics the way the conv epilogue hands them over: one row of (sum, sumsq)
+    part = torch.stack([y.sum((0, 2, 3)), (y * y).sum((0, 2, 3))], dim=1).reshape(1, C, 2).cuda()
+    f = lambda: torch.empty(C, device='cuda')
+    mean_d, invstd, scale, shift = f(), f(), f(), f()
+    rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    n = float(B * H * W)
+    gd, bd = gamma.cuda(), beta.cuda()      # keep the device copies alive across the asynchronous launch
+    L.check(L.lib().vqa_bn_finalize(L.stream(), L.ptr(part), 1, C, ctypes.c_double(n), L.ptr(gd),
+                                    L.ptr(bd), L.ptr(rm), L.ptr(rv), ctypes.c_float(0.1),
+                                    ctypes.c_float(1e-5), L.ptr(mean_d), L.ptr(invstd), L.ptr(scale), L.ptr(shift)),
+            'bn_finalize')
+    assert torch.allclose(mean_d.cpu(), mean, atol=1e-5)
+    assert torch.allclose(rv.cpu(), 0.9 + 0.1 * var * n / (n - 1), rtol=1e-4)
+    a = M.bn_act_pool(yd, scale, shift, pool)
+    err = (a.float().cpu().permute(0, 3, 1, 2) - a_ref.detach()).norm() / a_ref.detach().norm()
+    assert float(err) < (1e-6 if prec == 'fp32' else 4e-3)
+
+    dad = _nhwc(da, dt)
+    rows = L.lib().vqa_bn_bwd_rows(L.dt(yd), B, H, W, C, pool)
+    partb = torch.empty(rows, C, 2, device='cuda')
+    dgamma, dbeta, c1, c2 = f(), f(), f(), f()
+    dy = torch.empty_like(yd)
+    L.call('vqa_bn_bwd', L.dt(yd), 0, yd, dad, None, scale, shift, mean_d, invstd, None, None, partb, B, H, W, C, pool)
+    L.check(L.lib().vqa_bn_bwd_finalize(L.stream(), L.ptr(partb), rows, C, ctypes.c_double(n), L.ptr(dgamma),
+                                        L.ptr(dbeta), L.ptr(c1), L.ptr(c2)), 'bn_bwd_finalize')
+    L.call('vqa_bn_bwd', L.dt(yd), 1, yd, dad, dy, scale, shift, mean_d, invstd, c1, c2, None, B, H, W, C, pool)
+    rel = lambda u, v: float((u - v).norm() / v.norm())
+    assert rel(dgamma.cpu(), gr.grad) < tol
+    assert rel(dbeta.cpu(), br.grad) < tol
+    assert rel(dy.float().cpu().permute(0, 3, 1, 2), yr.grad) < tol
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', 2e-5), ('bf16', 6e-3)])
+@pytest.mark.parametrize('cin,cout,S,pad,pool', [(16, 16, 40, 0, 1), (16, 32, 21, 2, 0), (64, 64, 30, 0, 2),
+                                                 (128, 256, 14, 0, 0), (256, 256, 12, 0, 1)])
+def test_conv_block_fwd_bwd(prec, tol, cin, cout, S, pad, pool):
+    """One conv+BN+ReLU(+pool) block from IDENTICAL inputs, real-valued data: output and every gradient against
+    the oracle's formulas (for bf16: with the same storage rounding points, so the comparison is tight)."""
+    from vqa_amd import cnn as M
+    from oracle import vqa_oracle as O
+    torch.manual_seed(cin + cout + S)
+    dt = DT[prec]
+    emu = torch.bfloat16 if prec == 'bf16' else None
+    B = 3
+    x = torch.relu(torch.randn(B, cin, S, S)).to(dt).float()
+    w = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
+    b, gamma, beta = torch.randn(cout) * 0.1, torch.rand(cout) + 0.5, torch.randn(cout) * 0.3
+    xr, wr, gr, br = [t.clone().requires_grad_(True) for t in (x, w, gamma, beta)]
+    y = O._q(F.conv2d(xr, O._q(wr, emu), b, padding=pad), emu, True, True)
+    z, _, _ = O._BatchNormTrain.apply(y, gr, br)
+    a_ref = torch.relu(z)
+    a_ref = F.max_pool2d(a_ref, 2, 2) if pool == 1 else (F.avg_pool2d(a_ref, 2, 2) if pool == 2 else a_ref)
+    a_ref = O._q(a_ref, emu, True, False)
+    da = torch.randn_like(a_ref).to(dt).float()
+    a_ref.backward(da)
+
+    dev = lambda t: t.cuda()
+    rm, rv = torch.zeros(cout, device='cuda'), torch.ones(cout, device='cuda')
+    a, saved = M.block_fwd(_nhwc(x, dt), dev(w), dev(b), dev(gamma), dev(beta), rm, rv, pad, pool, True)
+    dx, dw, db, dg, dbt = M.block_bwd(_nhwc(da, dt), saved, dev(w), cin, pad, pool, True)
+    rel = lambda u, v: float((u.double().cpu() - v.double()).norm() / v.double().norm())
+    assert rel(a.float().permute(0, 3, 1, 2), a_ref.detach()) < tol
+    assert rel(dg, gr.grad) < tol and rel(dbt, br.grad) < tol
+    assert rel(dw, wr.grad) < tol
+    # dx: the oracle's gradient is not rounded on arrival at a leaf; bf16 storage adds 2^-9 per element
+    assert rel(dx.float().permute(0, 3, 1, 2), xr.grad) < (tol if prec == 'fp32' else 8e-3)
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('padding,pooling,size,B', [(2, 'max', 224, 2), (0, 'avg', 224, 2), (5, 'max', 224, 1),
+                                                   (2, 'max', 448, 1)])
+def test_cnn_stack_vs_oracle(prec, padding, pooling, size, B):
+    """Whole encoder, train and eval mode, forward + parameter gradients + running statistics vs the oracle."""
+    from vqa_amd import cnn as M, synth
+    from oracle import vqa_oracle as O
+    sd = synth.state_dict(42, 64, 50, 30)
+    csd = {k[4:]: v for k, v in sd.items() if k.startswith('cnn.')}
+    img = synth.images(7, B, size)
+    dv = torch.rand(B, {(2, 224): 25, (0, 224): 9, (5, 224): 49, (2, 448): 144}[(padding, size)], 256)
+    # oracle
+    p = {k: (v.clone().requires_grad_(True) if O.is_param(k) else v) for k, v in sd.items() if k.startswith('cnn.')}
+    new_stats = {}
+    emu = torch.bfloat16 if prec == 'bf16' else None   # bf16 kernels are checked against the same rounding points
+    v_ref = O.cnn_forward(p, img.float(), padding, pooling, True, new_stats, act_dtype=emu)
+    names = [k for k in p if O.is_param(k)]
+    g_ref = dict(zip(names, torch.autograd.grad((v_ref * dv).sum(), [p[k] for k in names])))
+    v_eval = O.cnn_forward(sd, img.float(), padding, pooling, False, act_dtype=emu)
+    # HIP
+    m = M.CNN(padding, pooling, precision=prec)
+    m.load_state_dict(csd)
+    m = m.cuda()
+    m.eval()
+    with torch.no_grad():
+        out_eval = m(img.cuda())
+    m.train()
+    out = m(img.cuda())
+    (out * dv.cuda()).sum().backward()
+    rel = lambda u, v: float((u.detach().cpu().double() - v.detach().double()).norm() / (v.detach().double().norm() + 1e-30))
+    tol_f, tol_g = (1e-4, 3e-2) if prec == 'fp32' else (5e-2, 5e-1)
+    assert rel(out_eval, v_eval) < tol_f
+    assert rel(out, v_ref) < tol_f
+    for k, buf in m.state_dict().items():
+        if 'running' in k:
+            assert rel(buf, new_stats['cnn.' + k]) < tol_f, k
+    worst = 0.0
+    for k, prm in m.named_parameters():
+        ref = g_ref['cnn.' + k]
+        if k.endswith('.bias') and int(k.split('.')[1]) in O.CONV_IDX:
+            assert float(prm.grad.abs().max()) == 0.0
+            continue
+        e = rel(prm.grad, ref)
+        worst = max(worst, e)
+        assert e < tol_g, (k, e)
+    print(flush=True); print(f'[{prec} pad{padding} {pooling} {size}] fwd {rel(out, v_ref):.2e} eval {rel(out_eval, v_eval):.2e} '
+          f'worst grad {worst:.2e}')

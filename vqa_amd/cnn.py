@@ -1,0 +1,229 @@
+"""Image encoder: drop-in for the reference's `cnn.CNN` (cnn.py:11-54), HIP-backed.
+
+Same constructor (`padding`, `pooling`), same `convolutions` nn.Sequential layout (so parameter / buffer names
+`convolutions.{0,1,3,4,7,8,...}.*` match a reference state_dict), same output `[B, k, 256]`.  The forward and
+backward of the whole stack run as ONE torch.autograd.Function whose kernels are hand-written HIP
+(vqa_amd/csrc/conv.hip, bn.hip) reached through the C-ABI library: NHWC activations, implicit-GEMM MFMA
+convolutions with BatchNorm statistics in the epilogue, fused BN+ReLU+pool apply, closed-form BN backward.
+
+precision: 'bf16' (bf16 activations/weights in the MFMA, fp32 accumulate, fp32 master weights and statistics)
+or 'fp32' (exact-f32 MFMA).  There is no CPU path: on a CPU tensor the module raises.
+"""
+import platform
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+CHANNELS = [3, 16, 16, 32, 32, 64, 64, 128, 128, 256, 256]      # reference cnn.py:23-40
+CONV_IDX = [0, 3, 7, 10, 14, 17, 21, 24, 28, 31]
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+CIN0_PAD = 16          # the 3 image channels are zero-padded to one MFMA k-group
+
+
+def pick_tile(oh, ow, mt_max=256, patch_max=640):
+    """(R, CW): output-tile rows x cols of one workgroup.  Fewest tiles first, then the smallest halo."""
+    best = None
+    for cw in range(1, min(ow, mt_max) + 1):
+        r = min(oh, mt_max // cw)
+        while r >= 1 and (r + 2) * (cw + 2) > patch_max:
+            r -= 1
+        if r < 1:
+            continue
+        tiles = -(-oh // r) * -(-ow // cw)
+        # shrink r as far as the tile count allows (less overhang)
+        while r > 1 and -(-oh // (r - 1)) * -(-ow // cw) == tiles:
+            r -= 1
+        key = (tiles, (r + 2) * (cw + 2))
+        if best is None or key < best[0]:
+            best = (key, (r, cw))
+    return best[1]
+
+
+def _kp(ck, dtype):
+    kc = 32 if dtype == torch.bfloat16 else 16
+    return (9 * ck + kc - 1) // kc * kc
+
+
+def _ck(cin, dtype):
+    return min(cin, 32 if dtype == torch.bfloat16 else 16)
+
+
+def pack_weights(w, cin_p, dtype, dgrad):
+    """torch-layout fp32 [Cout,Cin,3,3] -> k-contiguous slab for conv3x3_igemm (forward or data-gradient)."""
+    cout, cin = w.shape[0], w.shape[1]
+    red = cout if dgrad else cin_p
+    rows = cin_p if dgrad else cout
+    ck = _ck(red, dtype)
+    kp = _kp(ck, dtype)
+    out = torch.empty((red // ck) * rows * kp, device=w.device, dtype=dtype)
+    L.call('vqa_conv_pack', L.dt(out), w, out, cout, cin, cin_p, ck, kp, int(dgrad))
+    return out
+
+
+def conv_fwd(x, wpk, bias, cout, pad, want_stats):
+    """x NHWC [B,IH,IW,Cin] -> y [B,OH,OW,Cout] (+ partial BN statistics rows)."""
+    B, IH, IW, cin = x.shape
+    OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
+    R, CW = pick_tile(OH, OW)
+    y = torch.empty(B, OH, OW, cout, device=x.device, dtype=x.dtype)
+    stats = None
+    if want_stats:
+        rows = B * (-(-OH // R)) * (-(-OW // CW))
+        stats = torch.empty(rows, cout, 2, device=x.device, dtype=torch.float32)
+    L.call('vqa_conv3x3_fwd', L.dt(x), x, wpk, y, bias, stats, B, IH, IW, cin, OH, OW, cout, pad, R, CW)
+    return y, stats
+
+
+def conv_wgrad(x, dy, cin_real, pad):
+    B, IH, IW, cin = x.shape
+    _, OH, OW, cout = dy.shape
+    mt = 256 if x.dtype == torch.bfloat16 else 128
+    R, CW = pick_tile(OH, OW, mt, 640 if mt == 256 else 320)
+    tiles = B * (-(-OH // R)) * (-(-OW // CW))
+    ck = _ck(cin, x.dtype)
+    pairs = (-(-cout // 64)) * (cin // ck)
+    G = max(1, min(tiles, 2048 // pairs))
+    part = torch.empty(G, cout, 9, cin, device=x.device, dtype=torch.float32)
+    dw = torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)
+    L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw, G, B, IH, IW, cin, cin_real, OH, OW, cout, pad, R, CW)
+    return dw
+
+
+def bn_act_pool(y, scale, shift, pool):
+    B, H, W, C = y.shape
+    a = torch.empty(B, H // 2 if pool else H, W // 2 if pool else W, C, device=y.device, dtype=y.dtype)
+    L.call('vqa_bn_act_pool_fwd', L.dt(y), y, a, scale, shift, B, H, W, C, pool)
+    return a
+
+
+def to_nhwc(images, dtype):
+    B, C, H, W = images.shape
+    out = torch.empty(B, H, W, CIN0_PAD, device=images.device, dtype=dtype)
+    L.call('vqa_nchw_to_nhwc', L.dt(images), L.dt(out), images.contiguous(), out, B, C, H, W, CIN0_PAD)
+    return out
+
+
+def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training):
+    """conv3x3 -> BatchNorm -> ReLU -> (pool).  x NHWC.  Returns (a, saved) with saved = (x, y, scale, shift,
+    mean, invstd) for block_bwd."""
+    dev, dtype, cout = x.device, x.dtype, w.shape[0]
+    wpk = pack_weights(w, x.shape[3], dtype, dgrad=False)
+    y, stats = conv_fwd(x, wpk, bias, cout, pad, training)
+    scale = torch.empty(cout, device=dev, dtype=torch.float32)
+    shift, mean, invstd = torch.empty_like(scale), torch.empty_like(scale), torch.empty_like(scale)
+    if training:
+        count = float(y.shape[0] * y.shape[1] * y.shape[2])
+        L.check(L.lib().vqa_bn_finalize(L.stream(), L.ptr(stats), stats.shape[0], cout, L.ctypes.c_double(count),
+                                        L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv),
+                                        L.ctypes.c_float(BN_MOMENTUM), L.ctypes.c_float(BN_EPS), L.ptr(mean),
+                                        L.ptr(invstd), L.ptr(scale), L.ptr(shift)), 'vqa_bn_finalize')
+    else:
+        L.call('vqa_bn_eval_coeffs', cout, gamma, beta, rm, rv, BN_EPS, scale, shift)
+    a = bn_act_pool(y, scale, shift, pool)
+    return a, (x, y, scale, shift, mean, invstd)
+
+
+def block_bwd(d, saved, w, cin_real, pad, pool, need_dx):
+    """d = gradient w.r.t. the block output (NHWC, activation dtype).  Returns (dx, dw, dbias, dgamma, dbeta)."""
+    x, y, scale, shift, mean, invstd = saved
+    dev = y.device
+    B, H, W, C = y.shape
+    count = float(B * H * W)
+    rows = L.lib().vqa_bn_bwd_rows(L.dt(y), B, H, W, C, pool)
+    part = torch.empty(rows, C, 2, device=dev, dtype=torch.float32)
+    dgamma = torch.empty(C, device=dev, dtype=torch.float32)
+    dbeta, c1, c2 = torch.empty_like(dgamma), torch.empty_like(dgamma), torch.empty_like(dgamma)
+    dy = torch.empty_like(y)
+    L.call('vqa_bn_bwd', L.dt(y), 0, y, d, None, scale, shift, mean, invstd, None, None, part, B, H, W, C, pool)
+    L.check(L.lib().vqa_bn_bwd_finalize(L.stream(), L.ptr(part), rows, C, L.ctypes.c_double(count), L.ptr(dgamma),
+                                        L.ptr(dbeta), L.ptr(c1), L.ptr(c2)), 'vqa_bn_bwd_finalize')
+    L.call('vqa_bn_bwd', L.dt(y), 1, y, d, dy, scale, shift, mean, invstd, c1, c2, None, B, H, W, C, pool)
+    dw = conv_wgrad(x, dy, cin_real, pad)
+    # the conv bias feeds a training-mode BatchNorm: its gradient is identically zero (the reference produces
+    # rounding noise ~1e-7 of the weight-gradient scale here)
+    dbias = torch.zeros(C, device=dev, dtype=torch.float32)
+    dx = None
+    if need_dx:
+        wpk = pack_weights(w, x.shape[3], x.dtype, dgrad=True)
+        dx, _ = conv_fwd(dy, wpk, None, x.shape[3], 2 - pad, False)
+    return dx, dw, dbias, dgamma, dbeta
+
+
+class _CnnFunction(torch.autograd.Function):
+    """images [B,3,S,S] + the 40 parameters + 20 running buffers -> [B,k,256] fp32."""
+
+    @staticmethod
+    def forward(ctx, images, cfg, *tensors):
+        padding, pool_mode, training, dtype = cfg
+        params, buffers = tensors[:40], tensors[40:]
+        x = to_nhwc(images, dtype)
+        saved, meta = [], []
+        for li in range(10):
+            w, bias, gamma, beta = params[4 * li: 4 * li + 4]
+            pad = padding if li in (0, 2, 4, 6) else 0
+            pool = pool_mode if li % 2 == 1 else 0
+            x, sv = block_fwd(x, w, bias, gamma, beta, buffers[2 * li], buffers[2 * li + 1], pad, pool, training)
+            saved += list(sv)
+            meta.append((pad, pool))
+        ctx.save_for_backward(*saved, *params)
+        ctx.meta, ctx.cfg = meta, cfg
+        B, PH, PW, C = x.shape
+        return x.reshape(B, PH * PW, C).float()
+
+    @staticmethod
+    def backward(ctx, dout):
+        padding, pool_mode, training, dtype = ctx.cfg
+        if not training:
+            raise L.VqaHipError('CNN backward is implemented for training-mode BatchNorm only')
+        saved, params = ctx.saved_tensors[:60], ctx.saved_tensors[60:]
+        grads = [None] * 40
+        B, H, W, C = saved[55].shape
+        pool_last = ctx.meta[9][1]
+        d = dout.reshape(B, H // 2 if pool_last else H, W // 2 if pool_last else W, C).to(dtype).contiguous()
+        for li in range(9, -1, -1):
+            pad, pool = ctx.meta[li]
+            d, dw, db, dg, dbt = block_bwd(d, saved[6 * li: 6 * li + 6], params[4 * li], CHANNELS[li], pad, pool,
+                                           li > 0)
+            grads[4 * li: 4 * li + 4] = [dw, db, dg, dbt]
+        return (None, None, *grads, *([None] * 20))
+
+
+class CNN(nn.Module):
+    def __init__(self, padding=0, pooling='max', precision='bf16'):
+        super(CNN, self).__init__()
+        self.device = 'cuda:0' if torch.cuda.is_available() else 'cpu'
+        running_on_linux = 'Linux' in platform.platform()  # noqa: F841  (attribute parity with the reference)
+        self.padding, self.pooling, self.precision = padding, pooling, precision
+
+        def pool():
+            return nn.MaxPool2d(2, 2) if pooling == 'max' else nn.AvgPool2d(2, 2)
+
+        layers = []
+        for li in range(10):
+            pad = padding if li in (0, 2, 4, 6) else 0
+            layers += [nn.Conv2d(CHANNELS[li], CHANNELS[li + 1], kernel_size=3, padding=pad),
+                       nn.BatchNorm2d(CHANNELS[li + 1]), nn.ReLU()]
+            if li % 2 == 1:
+                layers.append(pool())
+        # The Sequential only HOLDS the parameters / buffers under the reference's names; it is never called.
+        self.convolutions = nn.Sequential(*layers)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise L.VqaHipError('vqa_amd.CNN runs on an MI355X only (no CPU fallback); move the model and inputs '
+                                'to cuda')
+        dtype = torch.bfloat16 if self.precision == 'bf16' else torch.float32
+        params, buffers = [], []
+        for ci in CONV_IDX:
+            conv, bn = self.convolutions[ci], self.convolutions[ci + 1]
+            params += [conv.weight, conv.bias, bn.weight, bn.bias]
+            buffers += [bn.running_mean, bn.running_var]
+        cfg = (self.padding, 1 if self.pooling == 'max' else 2, self.training, dtype)
+        out = _CnnFunction.apply(x, cfg, *params, *buffers)
+        if self.training:
+            with torch.no_grad():
+                for ci in CONV_IDX:
+                    self.convolutions[ci + 1].num_batches_tracked += 1
+        return out

@@ -1,0 +1,485 @@
+// 3x3 stride-1 convolution for the image encoder (reference cnn.py:23-40), NHWC, as implicit GEMM on MFMA.
+//
+//   conv3x3_igemm   forward (y = conv(x, W) + bias, with per-channel sum / sum-of-squares partials for the
+//                   following BatchNorm) and, with rotated/transposed packed weights and pad' = 2 - pad, the
+//                   data gradient (dgrad).  GEMM view: D[co][pixel] = sum_k Wp[co][k] * patch[k][pixel],
+//                   k = (tap, ci).  One workgroup = R x CW output pixels (<= 256) of one image x <= 64 output
+//                   channels; the input patch (R+2)x(CW+2) and the weight slab are staged in LDS per
+//                   input-channel chunk of 64 bytes, so every input byte is read from L2/HBM once per tile and
+//                   the 9 taps re-read it from LDS.
+//   conv3x3_wgrad   weight gradient dW[co][tap][ci] = sum_pixels dy[pixel][co] * x[pixel+tap][ci]: the GEMM
+//                   reduction runs over pixels, which is the slow axis of both NHWC operands, so bf16 fragments
+//                   are fetched with the transposing LDS read (ds_read_b64_tr_b16) and f32 ones with plain
+//                   4-byte reads.  Partials per workgroup, summed in fixed order by conv3x3_wgrad_reduce.
+//   pack kernels    torch-layout f32 weights [Cout][Cin][3][3] -> k-contiguous slabs for fwd and dgrad.
+#include "common.h"
+
+namespace {
+
+constexpr int PADB = 16;  // LDS row padding (bytes)
+
+struct ConvArgs {
+    const void* x;      // [B][IH][IW][Cin]
+    const void* w;      // packed [Cin/CK][Cout][KP]
+    void* y;            // [B][OH][OW][Cout]
+    const float* bias;  // [Cout] or null
+    float* stats;       // [tiles*B][Cout][2] partial (sum, sumsq) or null
+    int B, IH, IW, Cin, OH, OW, Cout, pad;
+    int R, CW, tiles_x, tiles_y;
+};
+
+template <typename T, int CK> struct ConvCfg {
+    static constexpr int VEC = Mma<T>::VEC;
+    static constexpr int KC = 4 * VEC;                       // k per MFMA chunk
+    static constexpr int KP = (9 * CK + KC - 1) / KC * KC;   // padded k per channel chunk
+    static constexpr int NS = KP / KC;                       // chunks per channel chunk
+    static constexpr int PXB = CK * (int)sizeof(T) + PADB;   // LDS bytes per patch pixel
+    static constexpr int WROWB = KP * (int)sizeof(T) + PADB; // LDS bytes per weight row
+    static constexpr int VPP = CK * (int)sizeof(T) / 16;     // 16-byte vectors per patch pixel
+};
+
+// ---------------------------------------------------------------------------------------------- igemm
+template <typename T, int CK, int NBF>
+__global__ __launch_bounds__(256) void conv3x3_igemm(ConvArgs a) {
+    using Cfg = ConvCfg<T, CK>;
+    constexpr int VEC = Cfg::VEC, KC = Cfg::KC, KP = Cfg::KP, NS = Cfg::NS, PXB = Cfg::PXB, WROWB = Cfg::WROWB,
+                  VPP = Cfg::VPP;
+    constexpr int NB = NBF * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int PW = a.CW + 2, PPIX = (a.R + 2) * PW;
+    unsigned char* patch = smem;
+    unsigned char* wl = smem + (PPIX * PXB + 15) / 16 * 16;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x, b = blockIdx.y, co0 = blockIdx.z * NB;
+    const int ty = tile / a.tiles_x, tx = tile % a.tiles_x;
+    const int oy0 = ty * a.R, ox0 = tx * a.CW;
+    const int MT = a.R * a.CW;
+    const T* x = static_cast<const T*>(a.x);
+    const T* w = static_cast<const T*>(a.w);
+
+    // per-fragment pixel decode (4 fragments of 16 consecutive tile pixels per wave)
+    int pbase[4], opix[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int m = (wave * 4 + f) * 16 + r;
+        int pr = 0, pc = 0;
+        bool ok = m < MT;
+        if (ok) { pr = m / a.CW; pc = m % a.CW; }
+        ok = ok && (oy0 + pr < a.OH) && (ox0 + pc < a.OW);
+        pbase[f] = (pr * PW + pc) * PXB;
+        opix[f] = ok ? ((b * a.OH + oy0 + pr) * a.OW + ox0 + pc) : -1;
+    }
+
+    f32x4 acc[4][NBF];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int n = 0; n < NBF; ++n) acc[f][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = a.Cin / CK;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        // ---- stage the input patch (zero outside the image) and the weight slab
+        for (int i = tid; i < PPIX * VPP; i += 256) {
+            const int px = i / VPP, vv = i % VPP;
+            const int py = px / PW, pxx = px % PW;
+            const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
+                v = *reinterpret_cast<const uint4*>(x + ((long)(b * a.IH + iy) * a.IW + ix) * a.Cin + ch * CK +
+                                                    vv * VEC);
+            *reinterpret_cast<uint4*>(patch + px * PXB + vv * 16) = v;
+        }
+        constexpr int WV = KP / VEC;  // vectors per weight row
+        const T* wsrc = w + ((long)ch * a.Cout + co0) * KP;
+        for (int i = tid; i < NB * WV; i += 256) {
+            const int row = i / WV, kv = i % WV;
+            *reinterpret_cast<uint4*>(wl + row * WROWB + kv * 16) =
+                *reinterpret_cast<const uint4*>(wsrc + (long)row * KP + kv * VEC);
+        }
+        __syncthreads();
+        // ---- MFMA over 9 taps x CK channels
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int k0 = s * KC + q * VEC;
+            int tap = k0 / CK;
+            const int c = k0 % CK;
+            tap = tap > 8 ? 8 : tap;  // padded k: weights are zero there, read any finite data
+            const int toff = ((tap / 3) * PW + (tap % 3)) * PXB + c * (int)sizeof(T);
+            uint4 fw[NBF], fp[4];
+#pragma unroll
+            for (int n = 0; n < NBF; ++n)
+                fw[n] = *reinterpret_cast<const uint4*>(wl + (n * 16 + r) * WROWB + k0 * (int)sizeof(T));
+#pragma unroll
+            for (int f = 0; f < 4; ++f) fp[f] = *reinterpret_cast<const uint4*>(patch + pbase[f] + toff);
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int n = 0; n < NBF; ++n) Mma<T>::mma(acc[f][n], fw[n], fp[f]);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: + bias, store (lane owns 4 consecutive channels of one pixel), BN partial statistics
+    T* y = static_cast<T*>(a.y);
+    float s1[NBF][4], s2[NBF][4];
+#pragma unroll
+    for (int n = 0; n < NBF; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[n][e] = s2[n][e] = 0.f;
+#pragma unroll
+    for (int n = 0; n < NBF; ++n) {
+        const int co = co0 + n * 16 + q * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = a.bias[co + e];
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            if (opix[f] < 0) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = to_f32(from_f32<T>(acc[f][n][e] + bv[e]));  // statistics of what is stored
+                s1[n][e] += v[e];
+                s2[n][e] += v[e] * v[e];
+            }
+            store_vec4<T>(y + (long)opix[f] * a.Cout + co, v);
+        }
+    }
+    if (a.stats) {
+        float* red = reinterpret_cast<float*>(smem);  // [4 waves][NB][2]; staging LDS is free after the last sync
+#pragma unroll
+        for (int n = 0; n < NBF; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t1 = sum16(s1[n][e]), t2 = sum16(s2[n][e]);
+                if (r == 0) {
+                    red[(wave * NB + n * 16 + q * 4 + e) * 2 + 0] = t1;
+                    red[(wave * NB + n * 16 + q * 4 + e) * 2 + 1] = t2;
+                }
+            }
+        __syncthreads();
+        if (tid < NB * 2) {
+            const float t = red[tid] + red[NB * 2 + tid] + red[2 * NB * 2 + tid] + red[3 * NB * 2 + tid];
+            const long blk = (long)b * gridDim.x + tile;
+            a.stats[(blk * a.Cout + co0) * 2 + tid] = t;
+        }
+    }
+}
+
+template <typename T, int CK, int NBF>
+int launch_igemm(hipStream_t s, const ConvArgs& a) {
+    using Cfg = ConvCfg<T, CK>;
+    const int PPIX = (a.R + 2) * (a.CW + 2);
+    size_t lds = (size_t)(PPIX * Cfg::PXB + 15) / 16 * 16 + (size_t)NBF * 16 * Cfg::WROWB;
+    if (lds < (size_t)4 * NBF * 16 * 2 * sizeof(float)) lds = (size_t)4 * NBF * 16 * 2 * sizeof(float);
+    if (lds > 160 * 1024) return VQA_ERR_ARG;
+    dim3 grid(a.tiles_x * a.tiles_y, a.B, a.Cout / (NBF * 16));
+    auto k = conv3x3_igemm<T, CK, NBF>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+template <typename T, int CK>
+int dispatch_nb(hipStream_t s, const ConvArgs& a) {
+    if (a.Cout % 64 == 0) return launch_igemm<T, CK, 4>(s, a);
+    if (a.Cout == 32) return launch_igemm<T, CK, 2>(s, a);
+    if (a.Cout == 16) return launch_igemm<T, CK, 1>(s, a);
+    return VQA_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------- wgrad
+struct WgradArgs {
+    const void* x;   // [B][IH][IW][Cin]
+    const void* dy;  // [B][OH][OW][Cout]
+    float* part;     // [G][Cout][9][Cin] partial sums
+    int B, IH, IW, Cin, OH, OW, Cout, pad;
+    int R, CW, tiles_x, tiles_y;
+};
+
+// One workgroup: NB = 64 output channels x CK input channels x 9 taps, looping over pixel tiles
+// t = blockIdx.x, blockIdx.x + gridDim.x, ...  Wave w owns the 16 output channels [16w, 16w+16).
+template <typename T, int CK>
+__global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
+    constexpr int VEC = Mma<T>::VEC, KC = 4 * VEC;
+    constexpr int PXB = CK * (int)sizeof(T) + PADB;
+    constexpr int NB = 64, DYB = NB * (int)sizeof(T) + PADB;
+    constexpr int VPP = CK * (int)sizeof(T) / 16, DVP = NB * (int)sizeof(T) / 16;
+    constexpr int CF = CK / 16;  // input-channel fragments
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int PW = a.CW + 2, PPIX = (a.R + 2) * PW, MT = a.R * a.CW;
+    const int MTP = (MT + KC - 1) / KC * KC;
+    unsigned char* patch = smem;
+    unsigned char* dyl = smem + (PPIX * PXB + 15) / 16 * 16;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int nco = (a.Cout + NB - 1) / NB;
+    const int co0 = (blockIdx.y % nco) * NB, ci0 = (blockIdx.y / nco) * CK;
+    const int cow = a.Cout - co0 < NB ? a.Cout - co0 : NB;  // valid output channels of this block
+    const T* x = static_cast<const T*>(a.x);
+    const T* dy = static_cast<const T*>(a.dy);
+
+    f32x4 acc[9][CF];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < CF; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int b = t / tiles, tl = t % tiles;
+        const int oy0 = (tl / a.tiles_x) * a.R, ox0 = (tl % a.tiles_x) * a.CW;
+        for (int i = tid; i < PPIX * VPP; i += 256) {
+            const int px = i / VPP, vv = i % VPP;
+            const int py = px / PW, pxx = px % PW;
+            const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
+                v = *reinterpret_cast<const uint4*>(x + ((long)(b * a.IH + iy) * a.IW + ix) * a.Cin + ci0 + vv * VEC);
+            *reinterpret_cast<uint4*>(patch + px * PXB + vv * 16) = v;
+        }
+        for (int i = tid; i < MTP * DVP; i += 256) {
+            const int m = i / DVP, vv = i % DVP;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m < MT && vv * VEC < cow) {
+                const int pr = m / a.CW, pc = m % a.CW;
+                if (oy0 + pr < a.OH && ox0 + pc < a.OW)
+                    v = *reinterpret_cast<const uint4*>(dy + ((long)(b * a.OH + oy0 + pr) * a.OW + ox0 + pc) * a.Cout +
+                                                        co0 + vv * VEC);
+            }
+            *reinterpret_cast<uint4*>(dyl + m * DYB + vv * 16) = v;
+        }
+        __syncthreads();
+        if (wave * 16 < cow) {
+            for (int ks = 0; ks < MTP; ks += KC) {
+                if constexpr (sizeof(T) == 2) {
+                    // bf16: lane i = 4*rq + p of a 16-lane group supplies the address of k-row rq, channels 4p..4p+3;
+                    // it receives channel i of 4 k-rows.  Two reads = the 8 k (pixels) of lane group q.
+                    const int rq = r >> 2, p = r & 3;
+                    uint4 fa;  // dy fragment: rows = co
+                    int poff[2];
+                    {
+                        bf16x4 lo, hi;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            int m = ks + q * 8 + h * 4 + rq;
+                            const unsigned char* ad = dyl + m * DYB + (wave * 16 + 4 * p) * 2;
+                            bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                (__attribute__((address_space(3))) bf16x4*)(ad));
+                            if (h == 0) lo = v; else hi = v;
+                            if (m >= MT) m = 0;
+                            poff[h] = ((m / a.CW) * PW + (m % a.CW)) * PXB + 4 * p * 2;
+                        }
+                        bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        fa = __builtin_bit_cast(uint4, f);
+                    }
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) {
+                        const int toff = ((tp / 3) * PW + (tp % 3)) * PXB;
+#pragma unroll
+                        for (int c = 0; c < CF; ++c) {
+                            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                (__attribute__((address_space(3))) bf16x4*)(patch + poff[0] + toff + c * 32));
+                            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                (__attribute__((address_space(3))) bf16x4*)(patch + poff[1] + toff + c * 32));
+                            bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            Mma<T>::mma(acc[tp][c], fa, __builtin_bit_cast(uint4, f));
+                        }
+                    }
+                } else {
+                    // f32: MFMA j of the chunk takes pixel k = ks + 4j + q
+                    float fa[4];
+                    int poff[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int m = ks + 4 * j + q;
+                        fa[j] = *reinterpret_cast<const float*>(dyl + m * DYB + (wave * 16 + r) * 4);
+                        if (m >= MT) m = 0;
+                        poff[j] = ((m / a.CW) * PW + (m % a.CW)) * PXB + r * 4;
+                    }
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) {
+                        const int toff = ((tp / 3) * PW + (tp % 3)) * PXB;
+#pragma unroll
+                        for (int c = 0; c < CF; ++c)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float fb = *reinterpret_cast<const float*>(patch + poff[j] + toff + c * 64);
+                                acc[tp][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb, acc[tp][c], 0, 0, 0);
+                            }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // D rows = co (4q+e), D cols = ci (r)
+    if (wave * 16 < cow) {
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int c = 0; c < CF; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = co0 + wave * 16 + q * 4 + e, ci = ci0 + c * 16 + r;
+                    a.part[(((long)blockIdx.x * a.Cout + co) * 9 + tp) * a.Cin + ci] = acc[tp][c][e];
+                }
+    }
+}
+
+// dW[co][ci][tap] (torch layout, ci < Cin_real) = sum_g part[g][co][tap][ci]
+__global__ void conv3x3_wgrad_reduce(const float* part, float* dw, int G, int Cout, int Cin, int Cin_real) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = Cout * 9 * Cin;
+    if (i >= n) return;
+    const int ci = i % Cin, tp = (i / Cin) % 9, co = i / (9 * Cin);
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += part[(long)g * n + i];
+    if (ci < Cin_real) dw[((long)co * Cin_real + ci) * 9 + tp] = s;
+}
+
+// ---------------------------------------------------------------------------------------------- packing
+// w [Cout][Cin][3][3] f32 -> fwd slab  [CinP/CK][Cout][KP],  k = tap*CK + c, ci = chunk*CK + c
+//                         -> dgrad slab [Cout/CKd][CinOut][KPd], k = tap'*CKd + c, co = chunk*CKd + c,
+//                            tap' = 8 - tap (180-degree rotation), output channel = ci
+template <typename T>
+__global__ void conv_pack(const float* w, T* out, int Cout, int Cin, int CinP, int CK, int KP, int dgrad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int rows = dgrad ? CinP : Cout;       // output-channel rows of the slab
+    const int red = dgrad ? Cout : CinP;        // reduction channels
+    const long n = (long)(red / CK) * rows * KP;
+    if (i >= n) return;
+    const int k = i % KP;
+    const int row = (i / KP) % rows;
+    const int ch = i / ((long)KP * rows);
+    float v = 0.f;
+    if (k < 9 * CK) {
+        const int tap = k / CK, c = ch * CK + k % CK;
+        if (!dgrad) {
+            if (c < Cin) v = w[((long)row * Cin + c) * 9 + tap];
+        } else {
+            if (row < Cin) v = w[((long)c * Cin + row) * 9 + (8 - tap)];
+        }
+    }
+    out[i] = from_f32<T>(v);
+}
+
+// images [B][C][H][W] (f32 / f16 / bf16) -> NHWC [B][H][W][CP] in T, channels >= C zero
+template <typename TI, typename T>
+__global__ void nchw_to_nhwc(const TI* in, T* out, int B, int C, int H, int W, int CP) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)B * H * W;
+    if (i >= n) return;
+    const long hw = (long)H * W;
+    const long b = i / hw, p = i % hw;
+    for (int c = 0; c < CP; ++c) {
+        float v = c < C ? to_f32(in[(b * C + c) * hw + p]) : 0.f;
+        out[i * CP + c] = from_f32<T>(v);
+    }
+}
+
+}  // namespace
+
+extern "C" int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked, void* y,
+                               const float* bias, float* stats, int B, int IH, int IW, int Cin, int OH, int OW,
+                               int Cout, int pad, int R, int CW) {
+    if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || R * CW > 256 ||
+        (R + 2) * (CW + 2) > 640)
+        return VQA_ERR_ARG;
+    ConvArgs a{x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, (OW + CW - 1) / CW,
+               (OH + R - 1) / R};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == VQA_BF16) {
+        if (Cin % 32 == 0) return dispatch_nb<bf16, 32>(s, a);
+        if (Cin == 16) return dispatch_nb<bf16, 16>(s, a);
+    } else if (dtype == VQA_F32) {
+        if (Cin % 16 == 0) return dispatch_nb<float, 16>(s, a);
+    }
+    return VQA_ERR_ARG;
+}
+
+// number of tile blocks the forward writes statistics for (rows of `stats`)
+extern "C" int vqa_conv3x3_stat_rows(int B, int OH, int OW, int R, int CW) {
+    return B * ((OW + CW - 1) / CW) * ((OH + R - 1) / R);
+}
+
+extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const void* dy, float* part, float* dw,
+                                 int G, int B, int IH, int IW, int Cin, int Cin_real, int OH, int OW, int Cout,
+                                 int pad, int R, int CW) {
+    if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || G < 1) return VQA_ERR_ARG;
+    WgradArgs a{x, dy, part, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, (OW + CW - 1) / CW, (OH + R - 1) / R};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int MT = R * CW, PPIX = (R + 2) * (CW + 2);
+    int status = VQA_ERR_ARG;
+    auto go = [&](auto kern, int CK, int esz) {
+        const int KC = 64 / esz;
+        const int MTP = (MT + KC - 1) / KC * KC;
+        size_t lds = (size_t)(PPIX * (CK * esz + PADB) + 15) / 16 * 16 + (size_t)MTP * (64 * esz + PADB);
+        if (lds > 160 * 1024) return VQA_ERR_ARG;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        dim3 grid(G, ((Cout + 63) / 64) * (Cin / CK));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+        return hipGetLastError() == hipSuccess ? VQA_OK : VQA_ERR_LAUNCH;
+    };
+    if (dtype == VQA_BF16) {
+        if (MT > 256) return VQA_ERR_ARG;
+        if (Cin % 32 == 0) status = go(conv3x3_wgrad<bf16, 32>, 32, 2);
+        else if (Cin == 16) status = go(conv3x3_wgrad<bf16, 16>, 16, 2);
+    } else if (dtype == VQA_F32) {
+        if (MT > 128) return VQA_ERR_ARG;
+        if (Cin % 16 == 0) status = go(conv3x3_wgrad<float, 16>, 16, 4);
+    }
+    if (status != VQA_OK) return status;
+    const int n = Cout * 9 * Cin;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((n + 255) / 256), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_conv_pack(void* stream, int dtype, const float* w, void* out, int Cout, int Cin, int CinP,
+                             int CK, int KP, int dgrad) {
+    const int rows = dgrad ? CinP : Cout, red = dgrad ? Cout : CinP;
+    if (red % CK) return VQA_ERR_ARG;
+    const long n = (long)(red / CK) * rows * KP;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == VQA_BF16)
+        hipLaunchKernelGGL(conv_pack<bf16>, grid, dim3(256), 0, s, w, static_cast<bf16*>(out), Cout, Cin, CinP, CK, KP, dgrad);
+    else if (dtype == VQA_F32)
+        hipLaunchKernelGGL(conv_pack<float>, grid, dim3(256), 0, s, w, static_cast<float*>(out), Cout, Cin, CinP, CK, KP, dgrad);
+    else
+        return VQA_ERR_ARG;
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_nchw_to_nhwc(void* stream, int in_dtype, int out_dtype, const void* in, void* out, int B, int C,
+                                int H, int W, int CP) {
+    const long n = (long)B * H * W;
+    dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define GO(TI, TO) hipLaunchKernelGGL((nchw_to_nhwc<TI, TO>), grid, dim3(256), 0, s, static_cast<const TI*>(in), \
+                                      static_cast<TO*>(out), B, C, H, W, CP)
+    if (out_dtype == VQA_F32) {
+        if (in_dtype == VQA_F32) GO(float, float);
+        else if (in_dtype == VQA_F16) GO(_Float16, float);
+        else if (in_dtype == VQA_BF16) GO(bf16, float);
+        else return VQA_ERR_ARG;
+    } else if (out_dtype == VQA_BF16) {
+        if (in_dtype == VQA_F32) GO(float, bf16);
+        else if (in_dtype == VQA_F16) GO(_Float16, bf16);
+        else if (in_dtype == VQA_BF16) GO(bf16, bf16);
+        else return VQA_ERR_ARG;
+    } else {
+        return VQA_ERR_ARG;
+    }
+#undef GO
+    CHECK_LAUNCH();
+    return VQA_OK;
+}

@@ -41,3 +41,32 @@ def rel_err(a, b):
     a = torch.as_tensor(np.asarray(a), dtype=torch.float64).reshape(-1)
     b = torch.as_tensor(np.asarray(b), dtype=torch.float64).reshape(-1)
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def fixture_files(tmp, classes, vocab_words=40):
+    """The tiny question JSON + label2ans pickle tests/golden/make_golden.py built the reference model from
+    (same words, so the vocabulary has the same 82 rows)."""
+    import json
+    import pickle
+    alphabet = 'abcdefghijklmnopqrstuvwxyz'
+    words = [alphabet[i % 26] + alphabet[(i // 26) % 26] + 'x' for i in range(vocab_words)]
+    qs = [{'question': ' '.join(words[(3 * i + j) % vocab_words] for j in range(6))} for i in range(2 * vocab_words)]
+    qpath = os.path.join(str(tmp), 'questions.json')
+    with open(qpath, 'w') as f:
+        json.dump({'questions': qs}, f)
+    lpath = os.path.join(str(tmp), f'label2ans_{classes}.pkl')
+    with open(lpath, 'wb') as f:
+        pickle.dump([f'ans{i}' for i in range(classes)], f)
+    return qpath, lpath
+
+
+def build_model(case, tmp, precision):
+    """The HIP-backed VQA for a golden case, loaded with the case's synthetic state dict."""
+    import vqa_model
+    qpath, lpath = fixture_files(tmp, case['classes'])
+    m = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': case['hidden'], 'n_layers': 1,
+                       'train_question_path': qpath}, lpath, 256, case['padding'], 0.0, case['pooling'], 'relu',
+                      precision=precision)
+    assert len(m.gru.word_idx_mappings) == case['vocab']
+    m.load_state_dict(case['sd'], strict=True)
+    return m

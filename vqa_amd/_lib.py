@@ -55,5 +55,5 @@ def call(name, *args):
         elif isinstance(a, float):
             conv.append(ctypes.c_float(a))
         else:
-            conv.append(ctypes.c_int(int(a)))
+            conv.append(ctypes.c_long(int(a)))   # x86-64: int and long params both read it correctly
     check(fn(*conv), name)

@@ -1,0 +1,515 @@
+// Small HBM-bound kernels around the MFMA GEMMs: weight_norm, embedding, GRU gates, attention softmax/pooling,
+// head elementwise pieces, soft-score BCE, soft accuracy, grad-norm clip + Adamax.
+// Reference call sites: gru.py:48-52,101-106; vqa_model.py:59-75 (weight_norm), :83-103 (head), :215 (loss),
+// :127-132 (accuracy), :259/:218/:266 (clip + Adamax).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <typename T> __device__ __forceinline__ float ld(const T* p, long i) { return to_f32(p[i]); }
+
+// ---------------------------------------------------------------------------------------- reductions
+// out[0] = sum_i a[i]*b[i]   (two launches: partials in double, then a fixed-order final sum)
+__global__ void dot_partial(const float* a, const float* b, long n, double* part) {
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        s += (double)a[i] * (double)b[i];
+    __shared__ double r[4];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = r[0] + r[1] + r[2] + r[3];
+}
+__global__ void dot_final(const double* part, int n, float* out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) out[0] = (float)s;
+}
+
+// out[n] (+)= sum_m X[m][n]
+template <typename T>
+__global__ void colsum(const T* x, int M, int N, int ldx, float* out) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;   // 4 row groups
+    float s = 0.f;
+    if (n < N)
+        for (int m = part; m < M; m += 4) s += to_f32(x[(long)m * ldx + n]);
+    __shared__ float r[4][64];
+    r[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && n < N) out[n] = r[0][threadIdx.x] + r[1][threadIdx.x] + r[2][threadIdx.x] + r[3][threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------- weight norm
+// W = v * (g / sqrt(sumsq)); writes an MFMA-dtype copy [out][ldw] and a transposed copy [in][ldt]
+template <typename T>
+__global__ void wn_apply(const float* v, const float* g, const float* sumsq, int out, int in, T* w, int ldw, T* wt,
+                         int ldt) {
+    __shared__ float tile[32][33];
+    const float s = g[0] / sqrtf(sumsq[0]);
+    const int o0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int o = o0 + r, i = i0 + tx;
+        float x = 0.f;
+        if (o < out && i < in) {
+            x = v[(long)o * in + i] * s;
+            w[(long)o * ldw + i] = from_f32<T>(x);
+        }
+        tile[r][tx] = x;
+    }
+    __syncthreads();
+    if (wt) {
+        for (int r = ty; r < 32; r += 8) {
+            const int i = i0 + r, o = o0 + tx;
+            if (i < in && o < out) wt[(long)i * ldt + o] = from_f32<T>(tile[tx][r]);
+        }
+    }
+}
+// dv = (g/n) * (dW - (dot/n^2) v),  dg = dot / n,  n = sqrt(sumsq), dot = <dW, v>
+__global__ void wn_bwd(const float* dw, const float* v, const float* g, const float* sumsq, const float* dot, long n,
+                       float* dv, float* dg) {
+    const float nrm = sqrtf(sumsq[0]);
+    const float a = g[0] / nrm, b = dot[0] / sumsq[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dv[i] = a * (dw[i] - b * v[i]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) dg[0] = dot[0] / nrm;
+}
+
+// cast / pad: dst[m][0..ldd) = src[m][0..N) then zeros
+template <typename TS, typename TD>
+__global__ void cast_pad(const TS* src, int M, int N, int lds, TD* dst, int ldd) {
+    const long total = (long)M * ldd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = i % ldd;
+        const long m = i / ldd;
+        dst[i] = from_f32<TD>(n < N ? to_f32(src[m * lds + n]) : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- embedding
+// X[t][b][0..ldx) = emb[q[b][t]][0..E), zero padded   (time-major so every GRU step reads a contiguous slab)
+template <typename T>
+__global__ void embed_fwd(const long* q, const float* emb, int B, int Tn, int E, T* x, int ldx) {
+    const int row = blockIdx.x;          // t*B + b
+    const int t = row / B, b = row % B;
+    const long id = q[(long)b * Tn + t];
+    for (int e = threadIdx.x; e < ldx; e += blockDim.x)
+        x[(long)row * ldx + e] = from_f32<T>(e < E ? emb[id * E + e] : 0.f);
+}
+// demb[q[b][t]][e] += dx[t*B+b][e]
+__global__ void embed_bwd(const long* q, const float* dx, int B, int Tn, int E, int lddx, float* demb) {
+    const int row = blockIdx.x;
+    const int t = row / B, b = row % B;
+    const long id = q[(long)b * Tn + t];
+    for (int e = threadIdx.x; e < E; e += blockDim.x) atomicAdd(&demb[id * E + e], dx[(long)row * lddx + e]);
+}
+
+// ---------------------------------------------------------------------------------------- GRU gates
+// gi, gh: [B][3H] (gate rows r,z,n; biases already added).  h' = (1-z) n + z h.   saved: r, z, n, hn = gh_n.
+template <typename T>
+__global__ void gru_gate_fwd(const float* gi, const float* gh, const float* hprev, int B, int H, float* hnew, T* hnew_t,
+                             float* save /* [B][4H] */) {
+    const long total = (long)B * H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = i % H;
+        const long b = i / H;
+        const float* gib = gi + b * 3 * H;
+        const float* ghb = gh + b * 3 * H;
+        const float r = sigmoidf_(gib[j] + ghb[j]);
+        const float z = sigmoidf_(gib[H + j] + ghb[H + j]);
+        const float hn = ghb[2 * H + j];
+        const float n = tanhf(gib[2 * H + j] + r * hn);
+        const float h = (1.f - z) * n + z * hprev[i];
+        hnew[i] = h;
+        hnew_t[i] = from_f32<T>(h);
+        float* s = save + b * 4 * H;
+        s[j] = r; s[H + j] = z; s[2 * H + j] = n; s[3 * H + j] = hn;
+    }
+}
+// dgi = [dr, dz, dn], dgh = [dr, dz, dn*r]  (MFMA dtype, [B][3H]);  dhprev = dh * z  (the W_hh term is added by a GEMM)
+template <typename T>
+__global__ void gru_gate_bwd(const float* dh, const float* save, const float* hprev, int B, int H, T* dgi, T* dgh,
+                             float* dhprev) {
+    const long total = (long)B * H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = i % H;
+        const long b = i / H;
+        const float* s = save + b * 4 * H;
+        const float r = s[j], z = s[H + j], n = s[2 * H + j], hn = s[3 * H + j];
+        const float g = dh[i];
+        const float dn = g * (1.f - z) * (1.f - n * n);
+        const float dz = g * (hprev[i] - n) * z * (1.f - z);
+        const float dr = dn * hn * r * (1.f - r);
+        T* a = dgi + b * 3 * H;
+        T* c = dgh + b * 3 * H;
+        a[j] = from_f32<T>(dr); a[H + j] = from_f32<T>(dz); a[2 * H + j] = from_f32<T>(dn);
+        c[j] = from_f32<T>(dr); c[H + j] = from_f32<T>(dz); c[2 * H + j] = from_f32<T>(dn * r);
+        dhprev[i] = g * z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- attention
+// One workgroup (256 threads) per batch element: s_k = a[b,k,:].w_s ; p = softmax_k(s) ; vhat = sum_k p_k v[b,k,:]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd(const T* a, const T* ws, const float* v, int K, int H, int D, float* p,
+                                                float* vhat, T* vhat_t) {
+    extern __shared__ float sm[];  // s[K]
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < K; k += 4) {
+        const T* row = a + ((long)b * K + k) * H;
+        float s = 0.f;
+        for (int j = lane; j < H; j += 64) s += to_f32(row[j]) * to_f32(ws[j]);
+        s = wave_sum(s);
+        if (lane == 0) sm[k] = s;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, sm[k]);
+    float den = 0.f;
+    for (int k = 0; k < K; ++k) den += __expf(sm[k] - mx);
+    const float inv = 1.f / den;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc += __expf(sm[k] - mx) * inv * v[((long)b * K + k) * D + d];
+        vhat[(long)b * D + d] = acc;
+        vhat_t[(long)b * D + d] = from_f32<T>(acc);
+    }
+    for (int k = threadIdx.x; k < K; k += blockDim.x) p[(long)b * K + k] = __expf(sm[k] - mx) * inv;
+}
+// dp_k = v[b,k,:].dvhat[b];  ds_k = p_k (dp_k - sum_j p_j dp_j);  dv[b,k,:] = p_k dvhat[b];
+// dpre[b,k,:] = ds_k * w_s * 1[a>0];  dws_part[b][:] = sum_k ds_k a[b,k,:]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd(const T* a, const T* ws, const float* v, const float* p,
+                                                const float* dvhat, int K, int H, int D, float* dv, T* dpre,
+                                                float* dws_part) {
+    extern __shared__ float sm[];  // ds[K]
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < K; k += 4) {
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += v[((long)b * K + k) * D + d] * dvhat[(long)b * D + d];
+        s = wave_sum(s);
+        if (lane == 0) sm[k] = s;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot += p[(long)b * K + k] * sm[k];
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) sm[k] = p[(long)b * K + k] * (sm[k] - dot);
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        const float pk = p[(long)b * K + k];
+        for (int d = threadIdx.x; d < D; d += blockDim.x) dv[((long)b * K + k) * D + d] = pk * dvhat[(long)b * D + d];
+    }
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        const float w = to_f32(ws[j]);
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float av = to_f32(a[((long)b * K + k) * H + j]);
+            acc += sm[k] * av;
+            dpre[((long)b * K + k) * H + j] = from_f32<T>(av > 0.f ? sm[k] * w : 0.f);
+        }
+        dws_part[(long)b * H + j] = acc;
+    }
+}
+// out[b][:] = sum_k x[b*K + k][:]
+template <typename T>
+__global__ void group_sum(const T* x, int B, int K, int H, float* out, T* out_t) {
+    const long total = (long)B * H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = i % H;
+        const long b = i / H;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += to_f32(x[(b * K + k) * H + j]);
+        out[i] = s;
+        out_t[i] = from_f32<T>(s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- head elementwise
+// m0 = fv * fq * mask  (mask may be null; mask already carries the 1/(1-p) dropout scale)
+template <typename T>
+__global__ void hadamard_fwd(const float* fv, const float* fq, const float* mask, long n, T* out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = from_f32<T>(fv[i] * fq[i] * (mask ? mask[i] : 1.f));
+}
+// dpre_v = dm0*mask*fq*1[fv>0], dpre_q = dm0*mask*fv*1[fq>0]     (fv, fq are post-ReLU)
+template <typename T>
+__global__ void hadamard_bwd(const float* dm0, const float* fv, const float* fq, const float* mask, long n, T* dpv,
+                             T* dpq) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float g = dm0[i] * (mask ? mask[i] : 1.f);
+        dpv[i] = from_f32<T>(fv[i] > 0.f ? g * fq[i] : 0.f);
+        dpq[i] = from_f32<T>(fq[i] > 0.f ? g * fv[i] : 0.f);
+    }
+}
+// out = g * mask * 1[act > 0]
+template <typename T>
+__global__ void relu_bwd(const float* g, const float* act, const float* mask, long n, T* out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = from_f32<T>(act[i] > 0.f ? g[i] * (mask ? mask[i] : 1.f) : 0.f);
+}
+// out = x * mask (f32 + MFMA-dtype copy)
+template <typename T>
+__global__ void mask_mul(const float* x, const float* mask, long n, T* out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = from_f32<T>(x[i] * (mask ? mask[i] : 1.f));
+}
+
+// ---------------------------------------------------------------------------------------- loss / accuracy
+// loss = sum max(x,0) - x t + log1p(exp(-|x|)) ; dx = sigmoid(x) - t     (logits [B][C] with row stride ldx)
+__global__ void bce_partial(const float* x, const float* t, int B, int C, int ldx, float* dx, double* part) {
+    double s = 0.0;
+    const long total = (long)B * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        const long b = i / C;
+        const float xv = x[b * ldx + c], tv = t[i];
+        const float e = __expf(-fabsf(xv));
+        s += (double)(fmaxf(xv, 0.f) - xv * tv + log1pf(e));
+        if (dx) {
+            const float sg = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+            dx[i] = sg - tv;
+        }
+    }
+    __shared__ double r[4];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = r[0] + r[1] + r[2] + r[3];
+}
+// acc_part[b] = target[b][argmax_c logits[b][c]]  (first maximum, as torch.argmax)
+__global__ void soft_acc_rows(const float* x, const float* t, int C, int ldx, float* out) {
+    const int b = blockIdx.x, lane = threadIdx.x;   // one wave per row
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = x[(long)b * ldx + c];
+        if (v > best) { best = v; bi = c; }
+    }
+    for (int o = 1; o < 64; o <<= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) out[b] = t[(long)b * C + bi];
+}
+__global__ void sum_f32(const float* x, int n, float* out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += (double)x[i];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) out[0] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------- clip + Adamax
+// coef = min(1, max_norm / (sqrt(sqsum) + 1e-6))      (nn.utils.clip_grad_norm_)
+__global__ void clip_coef(const float* sqsum, float max_norm, float* coef, float* total_norm) {
+    const float n = sqrtf(sqsum[0]);
+    total_norm[0] = n;
+    const float c = max_norm / (n + 1e-6f);
+    coef[0] = c < 1.f ? c : 1.f;
+}
+// torch.optim.Adamax, weight_decay 0:  m = b1 m + (1-b1) g ; u = max(b2 u, |g| + eps) ; p -= lr/(1-b1^t) m/u
+__global__ void adamax_step(float* p, const float* g, float* m, float* u, long n, const float* coef, float lr_t,
+                            float b1, float b2, float eps) {
+    const float c = coef ? coef[0] : 1.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gv = g[i] * c;
+        const float mv = b1 * m[i] + (1.f - b1) * gv;
+        const float uv = fmaxf(b2 * u[i], fabsf(gv) + eps);
+        m[i] = mv;
+        u[i] = uv;
+        p[i] -= lr_t * mv / uv;
+    }
+}
+
+int grid1d(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+#define ST static_cast<hipStream_t>(stream)
+#define BY_T(dtype, CALL_BF, CALL_F32) \
+    do { if ((dtype) == VQA_BF16) { CALL_BF; } else if ((dtype) == VQA_F32) { CALL_F32; } else return VQA_ERR_ARG; } while (0)
+
+// out[0] = <a, b>; `part` holds 256 doubles of scratch
+extern "C" int vqa_dot(void* stream, const float* a, const float* b, long n, double* part, float* out) {
+    hipLaunchKernelGGL(dot_partial, dim3(256), dim3(256), 0, ST, a, b, n, part);
+    hipLaunchKernelGGL(dot_final, dim3(1), dim3(64), 0, ST, part, 256, out);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_colsum(void* stream, int dtype, const void* x, int M, int N, int ldx, float* out) {
+    dim3 grid((N + 63) / 64);
+    BY_T(dtype, hipLaunchKernelGGL(colsum<bf16>, grid, dim3(256), 0, ST, (const bf16*)x, M, N, ldx, out),
+         hipLaunchKernelGGL(colsum<float>, grid, dim3(256), 0, ST, (const float*)x, M, N, ldx, out));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_wn_apply(void* stream, int dtype, const float* v, const float* g, const float* sumsq, int out,
+                            int in, void* w, int ldw, void* wt, int ldt) {
+    dim3 grid((in + 31) / 32, (out + 31) / 32);
+    BY_T(dtype, hipLaunchKernelGGL(wn_apply<bf16>, grid, dim3(256), 0, ST, v, g, sumsq, out, in, (bf16*)w, ldw, (bf16*)wt, ldt),
+         hipLaunchKernelGGL(wn_apply<float>, grid, dim3(256), 0, ST, v, g, sumsq, out, in, (float*)w, ldw, (float*)wt, ldt));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_wn_bwd(void* stream, const float* dw, const float* v, const float* g, const float* sumsq,
+                          const float* dot, long n, float* dv, float* dg) {
+    hipLaunchKernelGGL(wn_bwd, dim3(grid1d(n)), dim3(256), 0, ST, dw, v, g, sumsq, dot, n, dv, dg);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_cast_pad(void* stream, int src_dtype, int dst_dtype, const void* src, int M, int N, int lds,
+                            void* dst, int ldd) {
+    dim3 grid(grid1d((long)M * ldd));
+    if (src_dtype == VQA_F32 && dst_dtype == VQA_BF16)
+        hipLaunchKernelGGL((cast_pad<float, bf16>), grid, dim3(256), 0, ST, (const float*)src, M, N, lds, (bf16*)dst, ldd);
+    else if (src_dtype == VQA_F32 && dst_dtype == VQA_F32)
+        hipLaunchKernelGGL((cast_pad<float, float>), grid, dim3(256), 0, ST, (const float*)src, M, N, lds, (float*)dst, ldd);
+    else if (src_dtype == VQA_BF16 && dst_dtype == VQA_F32)
+        hipLaunchKernelGGL((cast_pad<bf16, float>), grid, dim3(256), 0, ST, (const bf16*)src, M, N, lds, (float*)dst, ldd);
+    else
+        return VQA_ERR_ARG;
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_embed_fwd(void* stream, int dtype, const long* q, const float* emb, int B, int T, int E, void* x,
+                             int ldx) {
+    BY_T(dtype, hipLaunchKernelGGL(embed_fwd<bf16>, dim3(B * T), dim3(128), 0, ST, q, emb, B, T, E, (bf16*)x, ldx),
+         hipLaunchKernelGGL(embed_fwd<float>, dim3(B * T), dim3(128), 0, ST, q, emb, B, T, E, (float*)x, ldx));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_embed_bwd(void* stream, const long* q, const float* dx, int B, int T, int E, int lddx, float* demb) {
+    hipLaunchKernelGGL(embed_bwd, dim3(B * T), dim3(128), 0, ST, q, dx, B, T, E, lddx, demb);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_gru_gate_fwd(void* stream, int dtype, const float* gi, const float* gh, const float* hprev, int B,
+                                int H, float* hnew, void* hnew_t, float* save) {
+    dim3 grid(grid1d((long)B * H));
+    BY_T(dtype, hipLaunchKernelGGL(gru_gate_fwd<bf16>, grid, dim3(256), 0, ST, gi, gh, hprev, B, H, hnew, (bf16*)hnew_t, save),
+         hipLaunchKernelGGL(gru_gate_fwd<float>, grid, dim3(256), 0, ST, gi, gh, hprev, B, H, hnew, (float*)hnew_t, save));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_gru_gate_bwd(void* stream, int dtype, const float* dh, const float* save, const float* hprev, int B,
+                                int H, void* dgi, void* dgh, float* dhprev) {
+    dim3 grid(grid1d((long)B * H));
+    BY_T(dtype, hipLaunchKernelGGL(gru_gate_bwd<bf16>, grid, dim3(256), 0, ST, dh, save, hprev, B, H, (bf16*)dgi, (bf16*)dgh, dhprev),
+         hipLaunchKernelGGL(gru_gate_bwd<float>, grid, dim3(256), 0, ST, dh, save, hprev, B, H, (float*)dgi, (float*)dgh, dhprev));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_attn_fwd(void* stream, int dtype, const void* a, const void* ws, const float* v, int B, int K,
+                            int H, int D, float* p, float* vhat, void* vhat_t) {
+    const size_t lds = (size_t)K * sizeof(float);
+    BY_T(dtype, hipLaunchKernelGGL(attn_fwd<bf16>, dim3(B), dim3(256), lds, ST, (const bf16*)a, (const bf16*)ws, v, K, H, D, p, vhat, (bf16*)vhat_t),
+         hipLaunchKernelGGL(attn_fwd<float>, dim3(B), dim3(256), lds, ST, (const float*)a, (const float*)ws, v, K, H, D, p, vhat, (float*)vhat_t));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_attn_bwd(void* stream, int dtype, const void* a, const void* ws, const float* v, const float* p,
+                            const float* dvhat, int B, int K, int H, int D, float* dv, void* dpre, float* dws_part) {
+    const size_t lds = (size_t)K * sizeof(float);
+    BY_T(dtype, hipLaunchKernelGGL(attn_bwd<bf16>, dim3(B), dim3(256), lds, ST, (const bf16*)a, (const bf16*)ws, v, p, dvhat, K, H, D, dv, (bf16*)dpre, dws_part),
+         hipLaunchKernelGGL(attn_bwd<float>, dim3(B), dim3(256), lds, ST, (const float*)a, (const float*)ws, v, p, dvhat, K, H, D, dv, (float*)dpre, dws_part));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_group_sum(void* stream, int dtype, const void* x, int B, int K, int H, float* out, void* out_t) {
+    dim3 grid(grid1d((long)B * H));
+    BY_T(dtype, hipLaunchKernelGGL(group_sum<bf16>, grid, dim3(256), 0, ST, (const bf16*)x, B, K, H, out, (bf16*)out_t),
+         hipLaunchKernelGGL(group_sum<float>, grid, dim3(256), 0, ST, (const float*)x, B, K, H, out, (float*)out_t));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_hadamard_fwd(void* stream, int dtype, const float* fv, const float* fq, const float* mask, long n,
+                                void* out) {
+    dim3 grid(grid1d(n));
+    BY_T(dtype, hipLaunchKernelGGL(hadamard_fwd<bf16>, grid, dim3(256), 0, ST, fv, fq, mask, n, (bf16*)out),
+         hipLaunchKernelGGL(hadamard_fwd<float>, grid, dim3(256), 0, ST, fv, fq, mask, n, (float*)out));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_hadamard_bwd(void* stream, int dtype, const float* dm0, const float* fv, const float* fq,
+                                const float* mask, long n, void* dpv, void* dpq) {
+    dim3 grid(grid1d(n));
+    BY_T(dtype, hipLaunchKernelGGL(hadamard_bwd<bf16>, grid, dim3(256), 0, ST, dm0, fv, fq, mask, n, (bf16*)dpv, (bf16*)dpq),
+         hipLaunchKernelGGL(hadamard_bwd<float>, grid, dim3(256), 0, ST, dm0, fv, fq, mask, n, (float*)dpv, (float*)dpq));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_relu_bwd(void* stream, int dtype, const float* g, const float* act, const float* mask, long n,
+                            void* out) {
+    dim3 grid(grid1d(n));
+    BY_T(dtype, hipLaunchKernelGGL(relu_bwd<bf16>, grid, dim3(256), 0, ST, g, act, mask, n, (bf16*)out),
+         hipLaunchKernelGGL(relu_bwd<float>, grid, dim3(256), 0, ST, g, act, mask, n, (float*)out));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_mask_mul(void* stream, int dtype, const float* x, const float* mask, long n, void* out) {
+    dim3 grid(grid1d(n));
+    BY_T(dtype, hipLaunchKernelGGL(mask_mul<bf16>, grid, dim3(256), 0, ST, x, mask, n, (bf16*)out),
+         hipLaunchKernelGGL(mask_mul<float>, grid, dim3(256), 0, ST, x, mask, n, (float*)out));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+// loss[0] = BCE-with-logits sum; dlogits (may be null) = sigmoid(x) - t.   part: 256 doubles of scratch
+extern "C" int vqa_bce_sum(void* stream, const float* logits, const float* target, int B, int C, int ldx,
+                           float* dlogits, double* part, float* loss) {
+    hipLaunchKernelGGL(bce_partial, dim3(256), dim3(256), 0, ST, logits, target, B, C, ldx, dlogits, part);
+    hipLaunchKernelGGL(dot_final, dim3(1), dim3(64), 0, ST, part, 256, loss);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+// acc[0] = sum_b target[b][argmax logits[b]];  rows: B floats of scratch
+extern "C" int vqa_soft_accuracy_sum(void* stream, const float* logits, const float* target, int B, int C, int ldx,
+                                     float* rows, float* acc) {
+    hipLaunchKernelGGL(soft_acc_rows, dim3(B), dim3(64), 0, ST, logits, target, C, ldx, rows);
+    hipLaunchKernelGGL(sum_f32, dim3(1), dim3(64), 0, ST, rows, B, acc);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+// Global-norm clip + Adamax over ONE flat fp32 parameter / gradient buffer, no host synchronisation.
+// state: m, u (n floats each); scratch: part (256 doubles), sq/coef/total_norm (1 float each).
+extern "C" int vqa_clip_adamax(void* stream, float* p, const float* g, float* m, float* u, long n, float max_norm,
+                               float lr, float b1, float b2, float eps, int step, double* part, float* sq,
+                               float* coef, float* total_norm) {
+    if (n <= 0 || step < 1) return VQA_ERR_ARG;
+    const float* cp = nullptr;
+    if (max_norm > 0.f) {
+        hipLaunchKernelGGL(dot_partial, dim3(256), dim3(256), 0, ST, g, g, n, part);
+        hipLaunchKernelGGL(dot_final, dim3(1), dim3(64), 0, ST, part, 256, sq);
+        hipLaunchKernelGGL(clip_coef, dim3(1), dim3(1), 0, ST, sq, max_norm, coef, total_norm);
+        cp = coef;
+    }
+    const float lr_t = lr / (1.f - powf(b1, (float)step));
+    hipLaunchKernelGGL(adamax_step, dim3(grid1d(n)), dim3(256), 0, ST, p, g, m, u, n, cp, lr_t, b1, b2, eps);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}

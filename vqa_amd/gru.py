@@ -1,0 +1,145 @@
+"""Question encoder: drop-in for the reference's `gru.GRU` (gru.py:23-106), HIP-backed.
+
+Same constructor, same parameter names (`word_embedding.weight`, `encoder.{weight,bias}_{ih,hh}_l0`), same text
+helpers (`preprocess_question_string`, `words_to_idx`), same output: the hidden state after the LAST of the T
+tokens (pads included, gru.py:105).  The vocabulary is built without torchtext: specials first, then words by
+descending count, ties alphabetical, min_freq 2 (the legacy torchtext.vocab.Vocab order, gru.py:39).
+
+Forward/backward: embedding gather -> one [T*B,E]x[E,3H] input-projection MFMA GEMM -> per-timestep recurrent
+GEMM + fused gate kernel; BPTT with saved gates, weight gradients as two reduction-over-(T*B) MFMA GEMMs.
+"""
+import json
+import platform
+import re
+from collections import defaultdict
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+NUMBERS = {'0': 'zero', '1': 'one', '2': 'two', '3': 'three', '4': 'four', '5': 'five', '6': 'six', '7': 'seven',
+           '8': 'eight', '9': 'nine', '10': 'ten'}
+
+
+def build_vocab(counts, min_freq=2, specials=('<unk>', '<pad>')):
+    words = sorted(counts.items(), key=lambda kv: kv[0])
+    words.sort(key=lambda kv: kv[1], reverse=True)
+    itos = list(specials) + [w for w, c in words if c >= min_freq and w not in specials]
+    return {w: i for i, w in enumerate(itos)}, itos
+
+
+class _GruParams(nn.Module):
+    """Holds nn.GRU's parameter names/shapes/init for one layer without instantiating nn.GRU (whose .cuda()
+    would route through MIOpen's weight flattening)."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        k = 1.0 / hidden_size ** 0.5
+        mk = lambda *shape: nn.Parameter(torch.empty(*shape).uniform_(-k, k))
+        self.weight_ih_l0 = mk(3 * hidden_size, input_size)
+        self.weight_hh_l0 = mk(3 * hidden_size, hidden_size)
+        self.bias_ih_l0 = mk(3 * hidden_size)
+        self.bias_hh_l0 = mk(3 * hidden_size)
+
+
+class _GruFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, dtype, emb, w_ih, w_hh, b_ih, b_hh):
+        B, T = q.shape
+        E, H = emb.shape[1], w_hh.shape[1]
+        dev = q.device
+        Ep = ops.pad8(E)
+        q = q.contiguous()
+        x = torch.empty(T * B, Ep, device=dev, dtype=dtype)
+        L.call('vqa_embed_fwd', L.dt(x), q, emb, B, T, E, x, Ep)
+        wih = ops.cast_pad(w_ih, dtype, Ep)                      # [3H, E] (row stride Ep)
+        whh = ops.cast_pad(w_hh, dtype)
+        gi = ops.gemm(x[:, :E], wih, bias=b_ih)                  # [T*B, 3H] fp32
+        h_f = torch.zeros(T + 1, B, H, device=dev, dtype=torch.float32)   # h_{-1} = 0, h_0 .. h_{T-1}
+        h_t = torch.zeros(T + 1, B, H, device=dev, dtype=dtype)
+        save = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
+        gh = torch.empty(B, 3 * H, device=dev, dtype=torch.float32)
+        for t in range(T):
+            ops.gemm(h_t[t], whh, out=gh, bias=b_hh)
+            L.call('vqa_gru_gate_fwd', L.dt(x), gi[t * B:(t + 1) * B], gh, h_f[t], B, H, h_f[t + 1], h_t[t + 1],
+                   save[t])
+        ctx.save_for_backward(q, x, h_f, h_t, save, w_ih, w_hh, emb)
+        ctx.dtype = dtype
+        return h_f[T].clone()
+
+    @staticmethod
+    def backward(ctx, dh_last):
+        q, x, h_f, h_t, save, w_ih, w_hh, emb = ctx.saved_tensors
+        dtype = ctx.dtype
+        B, T = q.shape
+        E, H = emb.shape[1], w_hh.shape[1]
+        dev = q.device
+        Ep = x.shape[1]
+        whh_T = ops.cast_pad(w_hh.t().contiguous(), dtype)       # [H, 3H]
+        wih_T = ops.cast_pad(w_ih.t().contiguous(), dtype)       # [E, 3H]
+        dgi = torch.empty(T * B, 3 * H, device=dev, dtype=dtype)
+        dgh = torch.empty(T * B, 3 * H, device=dev, dtype=dtype)
+        dh = dh_last.contiguous().float()
+        for t in range(T - 1, -1, -1):
+            dprev = torch.empty(B, H, device=dev, dtype=torch.float32)
+            L.call('vqa_gru_gate_bwd', L.dt(x), dh, save[t], h_f[t], B, H, dgi[t * B:(t + 1) * B],
+                   dgh[t * B:(t + 1) * B], dprev)
+            if t > 0:
+                ops.gemm(dgh[t * B:(t + 1) * B], whh_T, out=dprev, accumulate=True)   # += dgh_t @ W_hh
+            dh = dprev
+        hprev = h_t[:T].reshape(T * B, H)
+        dw_hh = ops.gemm(dgh, hprev, trans=True)                 # [3H, H]
+        dw_ih = ops.gemm(dgi, x[:, :E], trans=True)              # [3H, E]
+        db_ih, db_hh = ops.colsum(dgi), ops.colsum(dgh)
+        dx = ops.gemm(dgi, wih_T)                                # [T*B, E] fp32
+        demb = torch.zeros_like(emb)
+        L.call('vqa_embed_bwd', q, dx, B, T, E, dx.stride(0), demb)
+        return None, None, demb, dw_ih, dw_hh, db_ih, db_hh
+
+
+class GRU(nn.Module):
+    def __init__(self, word_embd_dim, hidden_dim, n_layers, train_question_path, precision='bf16'):
+        super(GRU, self).__init__()
+        if n_layers != 1:
+            raise ValueError('the HIP GRU implements the single-layer encoder every reference config uses')
+        running_on_linux = 'Linux' in platform.platform()  # noqa: F841
+        self.device = 'cuda:0' if torch.cuda.is_available() else 'cpu'
+        self.train_question_path = train_question_path
+        self.precision = precision
+        self.word_dict = self.get_vocabs_counts()
+        self.word_idx_mappings, self.idx_word_mappings = build_vocab(self.word_dict, min_freq=2)
+        self.word_embedding = nn.Embedding(len(self.word_idx_mappings), word_embd_dim)   # N(0,1), trainable
+        self.encoder = _GruParams(word_embd_dim, hidden_dim)
+
+    @staticmethod
+    def preprocess_question_string(question):
+        """reference gru.py:55-68: capitalise the first letter, lower the rest, digits 0-10 to words, any other
+        token containing a digit -> '<number>', strip non-alphanumerics."""
+        result = question[0].upper() + question[1:].lower()
+        words = [NUMBERS[word] if word in NUMBERS else word for word in result.split(' ')]
+        return [('<number>' if any(ch.isdigit() for ch in word) else re.sub(r'[\W_]+', '', word)) for word in words]
+
+    def get_vocabs_counts(self):
+        word_dict = defaultdict(int)
+        with open(self.train_question_path) as json_file:
+            for q_object in json.load(json_file)['questions']:
+                for word in self.preprocess_question_string(q_object['question']):
+                    word_dict[word] += 1
+        return word_dict
+
+    def words_to_idx(self, question: list):
+        """reference gru.py:87-99: indices, <unk> for unknown words, trimmed / <pad>-padded to 14."""
+        unk, pad = self.word_idx_mappings['<unk>'], self.word_idx_mappings['<pad>']
+        idx = [self.word_idx_mappings.get(word, unk) for word in question][:14]
+        return torch.tensor(idx + [pad] * (14 - len(idx))).long()
+
+    def forward(self, questions_batch):
+        if not questions_batch.is_cuda:
+            raise L.VqaHipError('vqa_amd.GRU runs on an MI355X only (no CPU fallback)')
+        dtype = torch.bfloat16 if self.precision == 'bf16' else torch.float32
+        e = self.encoder
+        return _GruFunction.apply(questions_batch, dtype, self.word_embedding.weight, e.weight_ih_l0, e.weight_hh_l0,
+                                  e.bias_ih_l0, e.bias_hh_l0)

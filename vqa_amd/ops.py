@@ -1,0 +1,109 @@
+"""Thin Python wrappers over the C-ABI entry points shared by the GRU, the fusion head, the loss and the optimizer.
+Every function launches hand-written HIP kernels on torch's current stream; nothing here computes on the CPU."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def gemm(A, B, trans=False, M=None, N=None, K=None, out=None, out_dtype=torch.float32, bias=None, rowadd=None,
+         group=1, act=0, accumulate=False, c2=None):
+    """NT: out[M,N] = A[M,K] @ B[N,K]^T.   TN (trans=True): out[M,N] = A[K,M]^T @ B[K,N].
+    A / B may be row-strided views (stride(1) == 1).  Epilogue: + bias[n] + rowadd[m // group, n], ReLU (act=1),
+    accumulate into `out`, optional bf16 copy `c2`."""
+    assert A.stride(1) == 1 and B.stride(1) == 1 and A.dtype == B.dtype
+    if trans:
+        K = A.shape[0] if K is None else K
+        M = A.shape[1] if M is None else M
+        N = B.shape[1] if N is None else N
+    else:
+        M = A.shape[0] if M is None else M
+        K = A.shape[1] if K is None else K
+        N = B.shape[0] if N is None else N
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=out_dtype)
+    assert out.stride(1) == 1
+    L.call('vqa_gemm', L.dt(A), int(trans), M, N, K, A, A.stride(0), B, B.stride(0), out, out.stride(0), L.dt(out),
+           bias, rowadd, group, act, int(accumulate), c2, c2.stride(0) if c2 is not None else 0)
+    return out
+
+
+_scratch = {}
+
+
+def scratch(dev):
+    """256 doubles + a few floats of per-device reduction scratch (stream-ordered use only)."""
+    key = str(dev)
+    if key not in _scratch:
+        _scratch[key] = torch.empty(256, device=dev, dtype=torch.float64)
+    return _scratch[key]
+
+
+def dot(a, b):
+    out = torch.empty(1, device=a.device, dtype=torch.float32)
+    L.check(L.lib().vqa_dot(L.stream(), L.ptr(a), L.ptr(b), ctypes.c_long(a.numel()), L.ptr(scratch(a.device)),
+                            L.ptr(out)), 'vqa_dot')
+    return out
+
+
+def colsum(x, M=None, N=None):
+    M = x.shape[0] if M is None else M
+    N = x.shape[1] if N is None else N
+    out = torch.empty(N, device=x.device, dtype=torch.float32)
+    L.call('vqa_colsum', L.dt(x), x, M, N, x.stride(0), out)
+    return out
+
+
+def cast_pad(src, dtype, ldd=None):
+    """[M,N] -> contiguous [M,ldd] in `dtype`, zero-padded columns; returns the [M,N] view."""
+    M, N = src.shape
+    ldd = N if ldd is None else ldd
+    if src.dtype == dtype and ldd == src.stride(0):
+        return src
+    dst = torch.empty(M, ldd, device=src.device, dtype=dtype)
+    L.call('vqa_cast_pad', L.dt(src), L.dt(dst), src, M, N, src.stride(0), dst, ldd)
+    return dst[:, :N]
+
+
+def weight_norm_fwd(v, g, dtype, transpose=True):
+    """weight_norm(dim=None) (reference vqa_model.py:59-75): W = g * v / ||v||_F.
+    Returns (W [out,in] view with padded row stride, W^T [in,out] view or None, sumsq)."""
+    out_f, in_f = v.shape
+    sumsq = dot(v, v)
+    w = torch.empty(out_f, pad8(in_f), device=v.device, dtype=dtype)
+    wt = torch.empty(in_f, pad8(out_f), device=v.device, dtype=dtype) if transpose else None
+    L.call('vqa_wn_apply', L.dt(w), v, g, sumsq, out_f, in_f, w, w.stride(0), wt, wt.stride(0) if transpose else 0)
+    return w[:, :in_f], (wt[:, :out_f] if transpose else None), sumsq
+
+
+def weight_norm_bwd(dw, v, g, sumsq):
+    """dW (fp32 [out,in] contiguous) -> (dg scalar, dv)."""
+    d = dot(dw, v)
+    dv = torch.empty_like(v)
+    dg = torch.empty((), device=v.device, dtype=torch.float32)
+    L.check(L.lib().vqa_wn_bwd(L.stream(), L.ptr(dw), L.ptr(v), L.ptr(g), L.ptr(sumsq), L.ptr(d),
+                               ctypes.c_long(v.numel()), L.ptr(dv), L.ptr(dg)), 'vqa_wn_bwd')
+    return dg, dv
+
+
+def bce_sum(logits, target, want_grad=True):
+    """sum-reduced BCE-with-logits (reference vqa_model.py:215) -> (loss [1], dlogits or None)."""
+    B, C = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    dl = torch.empty(B, C, device=logits.device, dtype=torch.float32) if want_grad else None
+    L.call('vqa_bce_sum', logits, target, B, C, logits.stride(0), dl, scratch(logits.device), loss)
+    return loss, dl
+
+
+def soft_accuracy_sum(logits, target):
+    """sum_b target[b, argmax logits[b]] on the device (reference vqa_model.py:127-130) -> tensor [1]."""
+    B, C = logits.shape
+    rows = torch.empty(B, device=logits.device, dtype=torch.float32)
+    acc = torch.empty(1, device=logits.device, dtype=torch.float32)
+    L.call('vqa_soft_accuracy_sum', logits, target.contiguous(), B, C, logits.stride(0), rows, acc)
+    return acc

@@ -1,0 +1,257 @@
+"""Drop-in for the reference's `vqa_model.VQA` / `vqa_model.evaluate` (vqa_model.py:20-141), HIP-backed.
+
+`VQA(gru_params, label2ans_path, img_feature_dim, padding, dropout, pooling, activation)` and
+`model(images_batch, questions_batch) -> logits [B, num_classes]` are unchanged; parameter names match the
+reference's state_dict (six weight-normalised linears expose `weight_g` (0-dim) / `weight_v` / `bias`).
+
+The attention + fusion + classifier head (vqa_model.py:83-103) is one torch.autograd.Function over hand-written
+HIP kernels: the q-term of the concat-attention linear is hoisted (W_att = [W_v | W_q], so
+relu(W_att [v;q] + b) = relu(W_v v + (W_q q + b)) is computed once per sample instead of once per region), the
+region softmax / weighted sum is one kernel per sample, every linear is an MFMA GEMM with bias/ReLU fused.
+"""
+import pickle
+import platform
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import cnn, gru, ops
+
+
+class RandomHorizontalFlip(nn.Module):
+    """torchvision.transforms.RandomHorizontalFlip as the reference uses it (vqa_model.py:41, :250): one draw
+    flips the whole batch along the width axis."""
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+
+    def forward(self, img):
+        return img.flip(-1) if torch.rand(1) < self.p else img
+
+
+class WeightNormLinear(nn.Module):
+    """Parameter container for weight_norm(nn.Linear(in, out, bias), dim=None): `weight_g` (0-dim), `weight_v`
+    [out, in] and `bias`, initialised like torch (g = ||v||_F).  The arithmetic lives in the HIP head."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        lin = nn.Linear(in_features, out_features, bias=bias)
+        self.in_features, self.out_features = in_features, out_features
+        if bias:
+            self.bias = nn.Parameter(lin.bias.detach().clone())
+        else:
+            self.register_parameter('bias', None)
+        self.weight_g = nn.Parameter(lin.weight.detach().norm().clone())
+        self.weight_v = nn.Parameter(lin.weight.detach().clone())
+
+
+HEAD_LAYERS = ['linear_inside_relu_attention', 'linear_after_relu_attention', 'linear_inside_relu_image',
+               'linear_inside_relu_question', 'linear_inside_relu_last', 'fc']
+
+
+class _HeadFunction(torch.autograd.Function):
+    """(v [B,k,D] fp32, q [B,H] fp32, weights) -> logits [B,C] fp32."""
+
+    @staticmethod
+    def forward(ctx, v, q, dtype, masks, g_att, v_att, b_att, g_s, v_s, g_img, v_img, b_img, g_q, v_q, b_q, g_last,
+                v_last, b_last, g_fc, v_fc):
+        B, K, D = v.shape
+        H, C = v_q.shape[0], v_fc.shape[0]
+        dev = v.device
+        v = v.contiguous()
+        q = q.contiguous()
+        mask1, mask2 = masks
+        W_att, W_att_T, ss_att = ops.weight_norm_fwd(v_att, g_att, dtype)      # [H, D+H]
+        w_s, _, ss_s = ops.weight_norm_fwd(v_s, g_s, dtype, transpose=False)   # [1, H]
+        W_img, W_img_T, ss_img = ops.weight_norm_fwd(v_img, g_img, dtype)
+        W_q, W_q_T, ss_q = ops.weight_norm_fwd(v_q, g_q, dtype)
+        W_last, W_last_T, ss_last = ops.weight_norm_fwd(v_last, g_last, dtype)
+        W_fc, W_fc_T, ss_fc = ops.weight_norm_fwd(v_fc, g_fc, dtype)
+
+        v_t = ops.cast_pad(v.reshape(B * K, D), dtype)
+        q_t = ops.cast_pad(q, dtype)
+        qa = ops.gemm(q_t, W_att[:, D:], bias=b_att)                                        # [B,H]
+        a = ops.gemm(v_t, W_att[:, :D], out_dtype=dtype, rowadd=qa, group=K, act=1)         # [B*K,H]
+        p = torch.empty(B, K, device=dev, dtype=torch.float32)
+        vhat = torch.empty(B, D, device=dev, dtype=torch.float32)
+        vhat_t = torch.empty(B, D, device=dev, dtype=dtype)
+        L.call('vqa_attn_fwd', L.dt(a), a, w_s, v, B, K, H, D, p, vhat, vhat_t)
+        fv = ops.gemm(vhat_t, W_img, bias=b_img, act=1)
+        fq = ops.gemm(q_t, W_q, bias=b_q, act=1)
+        m0 = torch.empty(B, H, device=dev, dtype=dtype)
+        L.call('vqa_hadamard_fwd', L.dt(m0), fv, fq, mask1, B * H, m0)
+        m = ops.gemm(m0, W_last, bias=b_last, act=1)
+        m_t = torch.empty(B, H, device=dev, dtype=dtype)
+        L.call('vqa_mask_mul', L.dt(m_t), m, mask2, B * H, m_t)
+        logits = ops.gemm(m_t, W_fc)
+        ctx.save_for_backward(v, q_t, v_t, a, w_s, p, vhat_t, fv, fq, m0, m, m_t, W_att_T, W_img_T, W_q_T, W_last_T,
+                              W_fc_T, ss_att, ss_s, ss_img, ss_q, ss_last, ss_fc, g_att, v_att, g_s, v_s, g_img, v_img,
+                              g_q, v_q, g_last, v_last, g_fc, v_fc, *[t for t in masks if t is not None])
+        ctx.dims, ctx.dtype, ctx.has_masks = (B, K, D, H, C), dtype, (mask1 is not None, mask2 is not None)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        (v, q_t, v_t, a, w_s, p, vhat_t, fv, fq, m0, m, m_t, W_att_T, W_img_T, W_q_T, W_last_T, W_fc_T, ss_att, ss_s,
+         ss_img, ss_q, ss_last, ss_fc, g_att, v_att, g_s, v_s, g_img, v_img, g_q, v_q, g_last, v_last, g_fc,
+         v_fc) = ctx.saved_tensors[:35]
+        extra = list(ctx.saved_tensors[35:])
+        mask1 = extra.pop(0) if ctx.has_masks[0] else None
+        mask2 = extra.pop(0) if ctx.has_masks[1] else None
+        B, K, D, H, C = ctx.dims
+        dtype, dev = ctx.dtype, dlogits.device
+        new = lambda *s, dt=dtype: torch.empty(*s, device=dev, dtype=dt)
+
+        dl_t = ops.cast_pad(dlogits.contiguous(), dtype, ops.pad8(C))            # [B,C] (padded rows)
+        dW_fc = ops.gemm(dl_t, m_t, trans=True)                                  # [C,H]
+        dm = ops.gemm(dl_t, W_fc_T)                                              # [B,H]
+        dpre_last = new(B, H)
+        L.call('vqa_relu_bwd', L.dt(dpre_last), dm, m, mask2, B * H, dpre_last)
+        dW_last = ops.gemm(dpre_last, m0, trans=True)
+        db_last = ops.colsum(dpre_last)
+        dm0 = ops.gemm(dpre_last, W_last_T)
+        dpv, dpq = new(B, H), new(B, H)
+        L.call('vqa_hadamard_bwd', L.dt(dpv), dm0, fv, fq, mask1, B * H, dpv, dpq)
+        dW_img = ops.gemm(dpv, vhat_t, trans=True)                               # [H,D]
+        db_img = ops.colsum(dpv)
+        dvhat = ops.gemm(dpv, W_img_T)                                           # [B,D]
+        dW_q = ops.gemm(dpq, q_t, trans=True)
+        db_q = ops.colsum(dpq)
+        dq = ops.gemm(dpq, W_q_T)                                                # [B,H]
+        # attention
+        dv = new(B * K, D, dt=torch.float32)
+        dpre_a = new(B * K, H)
+        dws_part = new(B, H, dt=torch.float32)
+        L.call('vqa_attn_bwd', L.dt(a), a, w_s, v, p, dvhat, B, K, H, D, dv, dpre_a, dws_part)
+        dW_s = ops.colsum(dws_part).reshape(1, H)
+        ops.gemm(dpre_a, W_att_T[:D], out=dv, accumulate=True)                   # += dpre_a @ W_v
+        dqa, dqa_t = new(B, H, dt=torch.float32), new(B, H)
+        L.call('vqa_group_sum', L.dt(dpre_a), dpre_a, B, K, H, dqa, dqa_t)
+        db_att = ops.colsum(dqa)
+        dW_att = new(H, D + H, dt=torch.float32)
+        ops.gemm(dpre_a, v_t, trans=True, out=dW_att[:, :D])
+        ops.gemm(dqa_t, q_t, trans=True, out=dW_att[:, D:])
+        ops.gemm(dqa_t, W_att_T[D:], out=dq, accumulate=True)                    # += dqa @ W_q-part
+        # weight-norm backward
+        dg_att, dv_att = ops.weight_norm_bwd(dW_att, v_att, g_att, ss_att)
+        dg_s, dv_s = ops.weight_norm_bwd(dW_s, v_s, g_s, ss_s)
+        dg_img, dv_img = ops.weight_norm_bwd(dW_img, v_img, g_img, ss_img)
+        dg_q, dv_q = ops.weight_norm_bwd(dW_q, v_q, g_q, ss_q)
+        dg_last, dv_last = ops.weight_norm_bwd(dW_last, v_last, g_last, ss_last)
+        dg_fc, dv_fc = ops.weight_norm_bwd(dW_fc, v_fc, g_fc, ss_fc)
+        return (dv.reshape(B, K, D), dq, None, None, dg_att, dv_att, db_att, dg_s, dv_s, dg_img, dv_img, db_img, dg_q,
+                dv_q, db_q, dg_last, dv_last, db_last, dg_fc, dv_fc)
+
+
+class VQA(nn.Module):
+    def __init__(self, gru_params: dict, label2ans_path: str, img_feature_dim: int, padding: int, dropout: float,
+                 pooling: str, activation: str, precision: str = 'bf16'):
+        """Arguments as the reference (vqa_model.py:21-32); `precision` ('bf16' | 'fp32') is the only addition."""
+        super(VQA, self).__init__()
+        running_on_linux = 'Linux' in platform.platform()  # noqa: F841
+        self.device = 'cuda:0' if torch.cuda.is_available() else 'cpu'
+        if activation != 'relu':
+            raise NotImplementedError("the HIP head implements activation='relu' (every reference run config); "
+                                      "the selu / AlphaDropout branch is not built")
+        self.precision = precision
+        self.cnn = cnn.CNN(padding=padding, pooling=pooling, precision=precision)
+        self.padding = padding
+        self.pooling = pooling
+        self.flip = RandomHorizontalFlip(p=0.5)
+        self.gru = gru.GRU(gru_params['word_embd_dim'], gru_params['question_hidden_dim'], gru_params['n_layers'],
+                           gru_params['train_question_path'], precision=precision)
+        self.word_embd_dim = gru_params['word_embd_dim']
+        self.question_hidden_dim = gru_params['question_hidden_dim']
+        self.hidden_dim = gru_params['question_hidden_dim']
+        self.n_layers = gru_params['n_layers']
+
+        with open(label2ans_path, 'rb') as f:
+            self.lbl2ans = pickle.load(f)
+        self.num_classes = len(self.lbl2ans)
+        self.activation = activation
+        self.dropout_p = dropout
+        H = self.hidden_dim
+        self.linear_inside_relu_attention = WeightNormLinear(img_feature_dim + H, H)
+        self.linear_after_relu_attention = WeightNormLinear(H, 1, bias=False)
+        self.linear_inside_relu_image = WeightNormLinear(img_feature_dim, H)
+        self.linear_inside_relu_question = WeightNormLinear(H, H)
+        self.linear_inside_relu_last = WeightNormLinear(H, H)
+        self.fc = WeightNormLinear(H, self.num_classes, bias=False)
+
+    def set_precision(self, precision):
+        self.precision = self.cnn.precision = self.gru.precision = precision
+        return self
+
+    def _dropout_mask(self, B, dev):
+        # inverted dropout (nn.Dropout, vqa_model.py:55): keep-mask scaled by 1/(1-p); identity at p=0 / eval
+        if not self.training or self.dropout_p <= 0.0:
+            return None
+        keep = 1.0 - self.dropout_p
+        return torch.empty(B, self.hidden_dim, device=dev).bernoulli_(keep).div_(keep)
+
+    def forward(self, images_batch, questions_batch):
+        if not images_batch.is_cuda:
+            raise L.VqaHipError('vqa_amd.VQA runs on an MI355X only: there is no CPU fallback for the hot path')
+        images_representation = self.cnn(images_batch)              # [B, k, d]
+        questions_representation = self.gru(questions_batch)        # [B, H]
+        dtype = torch.bfloat16 if self.precision == 'bf16' else torch.float32
+        B = images_batch.shape[0]
+        masks = (self._dropout_mask(B, images_batch.device), self._dropout_mask(B, images_batch.device))
+        a, s, i, qq, l, f = (getattr(self, n) for n in HEAD_LAYERS)
+        return _HeadFunction.apply(images_representation, questions_representation, dtype, masks,
+                                   a.weight_g, a.weight_v, a.bias, s.weight_g, s.weight_v, i.weight_g, i.weight_v,
+                                   i.bias, qq.weight_g, qq.weight_v, qq.bias, l.weight_g, l.weight_v, l.bias,
+                                   f.weight_g, f.weight_v)
+
+
+VQAModel = VQA   # the name BASELINE.json's north_star uses
+
+
+class _BceSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        loss, dl = ops.bce_sum(logits, target.contiguous(), want_grad=True)
+        ctx.save_for_backward(dl)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        (dl,) = ctx.saved_tensors
+        return dl * go, None
+
+
+class SoftScoreBCELoss(nn.Module):
+    """nn.BCEWithLogitsLoss(reduction='sum') against dense soft-score targets (vqa_model.py:215) as one fused HIP
+    kernel producing the loss and sigmoid(x) - t in a single pass over the logits."""
+
+    def forward(self, logits, target):
+        return _BceSum.apply(logits, target)
+
+
+def evaluate(dataloader, model, criterion, last_epoch_acc, dataset):
+    """reference vqa_model.py:106-141, same signature and return tuple.  The per-sample host loop
+    (vqa_model.py:129-130) is replaced by an on-device argmax + gather + sum: one scalar per batch."""
+    print(f"============ Evaluating on {'validation' if dataset.phase == 'val' else 'train'} set ============")
+    model.eval()
+    with torch.no_grad():
+        acc_sum = None
+        epoch_losses = list()
+        for i_batch, batch in enumerate(dataloader):
+            images_batch = batch['image'].cuda()
+            questions_batch = batch['question'].cuda()
+            target = batch['answer'].cuda()
+            output = model(images_batch, questions_batch)
+            loss = criterion(output, target)
+            epoch_losses.append(float(loss))
+            part = ops.soft_accuracy_sum(output, target)
+            acc_sum = part if acc_sum is None else acc_sum + part
+        accuracy = float(acc_sum) if acc_sum is not None else 0.0
+        acc = accuracy / dataset.original_length
+        print(f"{'Validation' if dataset.phase == 'val' else 'Train'} accuracy = {round(acc, 5)}")
+        cur_epoch_loss = float(np.mean(epoch_losses))
+        print(f"{'Validation' if dataset.phase == 'val' else 'Train'} loss = {round(cur_epoch_loss, 5)}")
+        acc_not_improved = not (acc > last_epoch_acc)
+        return cur_epoch_loss, acc_not_improved, acc

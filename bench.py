@@ -1,0 +1,212 @@
+"""Benchmark of the VQA training step on MI355X (BASELINE.json: "train samples/sec (node) at 1/2/4/8 MI355X").
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = the reference's training step (vqa_model.py:248-266) over one batch of synthetic VQA-v2-shaped input that
+is already resident in HBM: zero_grad -> batch flip -> forward (CNN + GRU + attention head) -> sum-BCE against soft
+scores -> backward -> (bucketed RCCL gradient all-reduce, SUM) -> clip_grad_norm 0.25 -> Adamax.
+Workload at N=1 = BASELINE.json configs[1]: bf16 training step, batch 256 per GPU, 224x224 images, 14 tokens,
+3129 answers, H=1024, V=10000 (weak scaling: 256 per GPU at every N).
+
+Rank 0 prints ONE JSON line; at N=1 it also carries
+  roofline     : the dominant kernel of the step, timed live with HIP events on the launching stream,
+  cpu_baseline : the CPU oracle's fwd+bwd step (config 0: fp32, batch 32) timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+MFMA_F32_PEAK_TFLOPS = 157.3
+GFLOP_PER_SAMPLE_TRAIN = 5.22   # 3 x (1.548 + 0.191) GFLOP, algorithm as written
+
+
+def make_fixture(tmp, vocab=10000, classes=3129):
+    """Question JSON whose vocabulary has exactly `vocab` rows (2 specials + 'What' + vocab-3 words seen twice) and a
+    label2ans pickle with `classes` answers (the reference's constructor reads both: gru.py:76, vqa_model.py:49)."""
+    import pickle
+    letters = 'abcdefghijklmnopqrstuvwxyz'
+
+    def word(i):
+        s = ''
+        for _ in range(4):
+            s += letters[i % 26]
+            i //= 26
+        return 'w' + s
+
+    words = [word(i) for i in range(vocab - 3)]
+    qs = []
+    for rep in range(2):
+        for i in range(0, len(words), 13):
+            qs.append({'question': 'what ' + ' '.join(words[i:i + 13])})
+    qpath, lpath = os.path.join(tmp, 'questions.json'), os.path.join(tmp, 'label2ans.pkl')
+    with open(qpath, 'w') as f:
+        json.dump({'questions': qs}, f)
+    with open(lpath, 'wb') as f:
+        pickle.dump([f'answer{i}' for i in range(classes)], f)
+    return qpath, lpath
+
+
+def cpu_baseline(hidden, classes, vocab, seconds=20.0):
+    """The CPU oracle's training step (fwd+bwd, fp32, batch 32 = BASELINE.json configs[0]) on this box's host cores."""
+    import torch
+    from oracle import vqa_oracle as O
+    from vqa_amd import synth
+    threads = min(16, os.cpu_count() or 1)       # the box's CPU share for one GPU is 16
+    torch.set_num_threads(threads)
+    B = 32
+    sd = synth.state_dict(42, hidden, classes, vocab)
+    img, q, t = synth.images(1234, B, 224), synth.questions(1234, B, 14, vocab), synth.targets(1234, B, classes)
+    times = []
+    t_end = time.perf_counter() + seconds
+    for i in range(12):
+        t0 = time.perf_counter()
+        O.train_step_grads(sd, img, q, t, 2, 'max')
+        times.append(time.perf_counter() - t0)
+        if i >= 3 and time.perf_counter() > t_end:
+            break
+    times = sorted(times[2:]) if len(times) > 3 else sorted(times)
+    med = times[len(times) // 2]
+    return {'value': round(B / med, 2), 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+            'sample': f'oracle fwd+bwd, fp32, batch {B}, 224x224, T=14, C={classes}, H={hidden}; median of '
+                      f'{len(times)} steps after 2 warm-up'}
+
+
+def roofline_leg(trainer, batch):
+    """One extra, instrumented step: HIP events around every C-ABI call on the launching stream; picks the kernel
+    with the largest total device time and prices it against its binding roofline."""
+    from vqa_amd import _lib as L
+    L.profile_start()
+    trainer.step(*batch)
+    prof = L.profile_stop()
+    totals = {k: sum(ms for ms, _ in v) for k, v in prof.items()}
+    # conv3x3_fwd serves both the forward conv and the data gradient; keep them apart
+    rows = {}
+    for name, recs in prof.items():
+        for ms, tag in recs:
+            key = name if not tag else f"{name}[{tag['kind']}]"
+            r = rows.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
+            r['ms'] += ms
+            r['n'] += 1
+            if tag:
+                r['flops'] += tag['flops']
+                r['bytes'] += tag['bytes']
+    dom = max((k for k in rows if rows[k]['bytes'] > 0), key=lambda k: rows[k]['ms'])
+    r = rows[dom]
+    gbs = r['bytes'] / (r['ms'] * 1e-3) / 1e9
+    tfl = r['flops'] / (r['ms'] * 1e-3) / 1e12
+    intensity = r['flops'] / r['bytes']
+    bound = 'mfma' if intensity > MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9) else 'hbm'
+    out = {'kernel': dom, 'bound': bound, 'launches_per_step': r['n'], 'avg_launch_ms': round(r['ms'] / r['n'], 4),
+           'traffic': None, 'tflops': round(tfl, 2), 'gbs': round(gbs, 1)}
+    if bound == 'hbm':
+        out.update(achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
+    else:
+        out.update(achieved=round(tfl, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s',
+                   frac=round(tfl / MFMA_BF16_PEAK_TFLOPS, 4))
+    breakdown = {k: round(v['ms'], 3) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]['ms'])[:12]}
+    return out, breakdown, sum(totals.values())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--hidden', type=int, default=1024)
+    ap.add_argument('--image', type=int, default=224)
+    ap.add_argument('--tokens', type=int, default=14)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', action='store_true', help='also print the per-kernel time table to stderr')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)     # RCCL over xGMI
+
+    from vqa_amd import synth
+    from vqa_amd.optim import Trainer
+    import vqa_model
+
+    classes, vocab = 3129, 10000
+    with tempfile.TemporaryDirectory() as tmp:
+        qpath, lpath = make_fixture(tmp, vocab, classes)
+        torch.manual_seed(42)                                  # module-default inits, as the reference (vqa_model.py:334)
+        model = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': args.hidden, 'n_layers': 1,
+                               'train_question_path': qpath}, lpath, 256, 2, 0.0, 'max', 'relu',
+                              precision=args.precision)
+    assert len(model.gru.word_idx_mappings) == vocab, len(model.gru.word_idx_mappings)
+    model = model.to(dev).train()
+    trainer = Trainer(model, lr=2e-3, max_norm=0.25)
+    B = args.batch
+    seed = 1234 + rank                                          # every rank its own shard of the global batch
+    batch = (synth.images(seed, B, args.image).to(dev), synth.questions(seed, B, args.tokens, vocab).to(dev),
+             synth.targets(seed, B, classes).to(dev))
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = trainer.step(*batch)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(*batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    final_loss = float(loss)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    result = {
+        'metric': 'train samples/sec (node)', 'value': round(value, 1), 'unit': 'samples/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+        'config': {'workload': 'BASELINE.json configs[1]: VQA training step (fwd+bwd+clip+Adamax), '
+                               f'{args.precision}, batch {B}/GPU, {args.image}x{args.image} images, {args.tokens} tokens, '
+                               f'{classes} answers, H={args.hidden}, V={vocab}, padding 2, max-pool, dropout 0',
+                   'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}',
+                   'weights': 'module-default init, seed 42', 'final_loss': round(final_loss, 3)},
+        'step_tflops_algorithmic': round(value * GFLOP_PER_SAMPLE_TRAIN / 1e3, 2),
+    }
+    if rank == 0 and world == 1:
+        roof, breakdown, dev_ms = roofline_leg(trainer, batch)
+        result['roofline'] = roof
+        result['device_ms_in_kernels'] = round(dev_ms, 3)
+        if args.breakdown:
+            print(json.dumps(breakdown, indent=1), file=sys.stderr)
+        if not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(args.hidden, classes, vocab)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

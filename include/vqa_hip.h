@@ -1,0 +1,139 @@
+/* C-ABI of libvqa_hip.so: the hand-written HIP (gfx950 / MI355X) kernels behind the drop-in VQA model.
+ *
+ * The reference (GalGoldstein/vqa) is pure Python and has no FFI of its own: its hot path is a chain of stock
+ * torch.nn modules.  Each entry point below replaces the arithmetic of the torch call site(s) cited beside it
+ * (file:line under the reference tree).  The Python binding is vqa_amd/_lib.py (ctypes); INTEGRATION.md shows it.
+ *
+ * Conventions
+ *   - every function returns 0 on success, 1 = bad argument, 2 = launch failure; nothing throws across the ABI;
+ *   - `stream` is a hipStream_t (PyTorch's current stream); all work is asynchronous on it; the library keeps no
+ *     state, caches no stream or device, allocates nothing, and is re-entrant (autograd worker threads call it);
+ *   - the caller owns every buffer (inputs, outputs, workspaces, saved-for-backward tensors), all device memory;
+ *   - dtype codes: 0 = f32, 1 = bf16, 2 = f16 (image input only).  "T" below = the activation / MFMA dtype;
+ *   - activations are NHWC; matrices are row-major with an explicit leading dimension in elements.
+ */
+#ifndef VQA_HIP_H
+#define VQA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- image encoder (reference cnn.py:23-54) */
+
+/* [B][C][H][W] images (f32/f16/bf16; dataset.py:96-98 stores f16) -> NHWC [B][H][W][CP] in T, channels >= C zero. */
+int vqa_nchw_to_nhwc(void* stream, int in_dtype, int out_dtype, const void* in, void* out, int B, int C, int H,
+                     int W, int CP);
+
+/* torch-layout f32 conv weight [Cout][Cin][3][3] -> k-contiguous slab for vqa_conv3x3_fwd.
+ * dgrad = 0: [CinP/CK][Cout][KP], k = tap*CK + c.   dgrad = 1: rotated 180 deg + transposed, for the data gradient. */
+int vqa_conv_pack(void* stream, int dtype, const float* w, void* out, int Cout, int Cin, int CinP, int CK, int KP,
+                  int dgrad);
+
+/* nn.Conv2d(k=3, stride 1, padding=pad) forward (cnn.py:23-40) as implicit GEMM on MFMA; also the data gradient
+ * when called on dy with a dgrad slab and pad' = 2 - pad.  y = conv(x) + bias.  `stats` (may be NULL) receives one
+ * row of per-channel (sum, sum of squares) of y per workgroup for the BatchNorm that follows:
+ * vqa_conv3x3_stat_rows() rows of [Cout][2].  R x CW (<= 256 pixels) is the output tile of one workgroup. */
+int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked, void* y, const float* bias,
+                    float* stats, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW);
+int vqa_conv3x3_stat_rows(int B, int OH, int OW, int R, int CW);
+
+/* Conv2d weight gradient (autograd of cnn.py:23-40): dw [Cout][Cin_real][3][3] f32 = sum over pixels of dy (x) x.
+ * `part` is a [G][Cout][9][Cin] f32 workspace (G workgroup groups, summed in fixed order). */
+int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const void* dy, float* part, float* dw, int G, int B,
+                      int IH, int IW, int Cin, int Cin_real, int OH, int OW, int Cout, int pad, int R, int CW);
+
+/* nn.BatchNorm2d training statistics (cnn.py:23-40; eps 1e-5, momentum 0.1): from the conv partials to mean,
+ * invstd, scale = gamma*invstd, shift = beta - mean*scale; running_mean / running_var updated in place
+ * (unbiased variance); running_* may be NULL. */
+int vqa_bn_finalize(void* stream, const float* part, int rows, int C, double count, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                    float* mean, float* invstd, float* scale, float* shift);
+/* eval-mode BatchNorm2d: scale / shift from the running statistics. */
+int vqa_bn_eval_coeffs(void* stream, int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift);
+/* BatchNorm apply + nn.ReLU + nn.MaxPool2d(2,2) / nn.AvgPool2d(2,2) (cnn.py:23-41): pool 0 none, 1 max, 2 avg. */
+int vqa_bn_act_pool_fwd(void* stream, int dtype, const void* y, void* a, const float* scale, const float* shift,
+                        int B, int H, int W, int C, int pool);
+/* Backward of pool + ReLU + BatchNorm (autograd of cnn.py:23-41).  apply = 0: partial sums of dz and dz*xhat into
+ * `part` (vqa_bn_bwd_rows() rows of [C][2]); apply = 1: dy = scale*(dz - c1 - xhat*c2). */
+int vqa_bn_bwd_rows(int dtype, int B, int H, int W, int C, int pool);
+int vqa_bn_bwd(void* stream, int dtype, int apply, const void* y, const void* dout, void* dy, const float* scale,
+               const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2,
+               float* part, int B, int H, int W, int C, int pool);
+int vqa_bn_bwd_finalize(void* stream, const float* part, int rows, int C, double count, float* dgamma, float* dbeta,
+                        float* c1, float* c2);
+
+/* ---------------------------------------------------------------- linears (gru.py:51-52, vqa_model.py:59-103) */
+
+/* MFMA GEMM with fused epilogue.  trans = 0: C[M,N] = A[M,K] * B[N,K]^T (nn.Linear forward, input gradients with a
+ * pre-transposed weight).  trans = 1: C[M,N] = A[K,M]^T * B[K,N] (weight gradients).  Epilogue: + bias[n],
+ * + rowadd[m / rowadd_group][n], ReLU (act = 1), C += (accumulate = 1), optional bf16 copy C2. */
+int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+             void* C, int ldc, int c_dtype, const float* bias, const float* rowadd, int rowadd_group, int act,
+             int accumulate, void* C2, int ldc2);
+/* out[0] = <a, b> (f32 data, f64 accumulation); part = 256 doubles of scratch. */
+int vqa_dot(void* stream, const float* a, const float* b, long n, double* part, float* out);
+/* out[n] = sum_m x[m][n] (bias gradients). */
+int vqa_colsum(void* stream, int dtype, const void* x, int M, int N, int ldx, float* out);
+/* weight_norm(dim=None) forward (vqa_model.py:59-75): W = v * g / sqrt(sumsq) as a T copy and a transposed T copy
+ * (wt may be NULL). */
+int vqa_wn_apply(void* stream, int dtype, const float* v, const float* g, const float* sumsq, int out, int in,
+                 void* w, int ldw, void* wt, int ldt);
+/* weight_norm backward: dv = (g/n)(dW - (dot/n^2) v), dg = dot/n with n = sqrt(sumsq), dot = <dW, v>. */
+int vqa_wn_bwd(void* stream, const float* dw, const float* v, const float* g, const float* sumsq, const float* dot,
+               long n, float* dv, float* dg);
+/* dtype conversion with zero-padded leading dimension. */
+int vqa_cast_pad(void* stream, int src_dtype, int dst_dtype, const void* src, int M, int N, int lds, void* dst,
+                 int ldd);
+
+/* ---------------------------------------------------------------- question encoder (gru.py:48-52, :101-106) */
+
+/* nn.Embedding gather (gru.py:103), time-major: x[t*B + b][0..ldx) = emb[q[b][t]], zero padded; q is int64 [B][T]. */
+int vqa_embed_fwd(void* stream, int dtype, const long* q, const float* emb, int B, int T, int E, void* x, int ldx);
+/* its backward: demb[q[b][t]] += dx[t*B + b] (demb pre-zeroed). */
+int vqa_embed_bwd(void* stream, const long* q, const float* dx, int B, int T, int E, int lddx, float* demb);
+/* nn.GRU cell gates (gru.py:104): r, z, n and h' = (1-z) n + z h from the two projections gi, gh ([B][3H], biases
+ * included); save = [B][4H] (r, z, n, W_hn h + b_hn) for the backward. */
+int vqa_gru_gate_fwd(void* stream, int dtype, const float* gi, const float* gh, const float* hprev, int B, int H,
+                     float* hnew, void* hnew_t, float* save);
+int vqa_gru_gate_bwd(void* stream, int dtype, const float* dh, const float* save, const float* hprev, int B, int H,
+                     void* dgi, void* dgh, float* dhprev);
+
+/* ---------------------------------------------------------------- attention / fusion head (vqa_model.py:83-103) */
+
+/* vqa_model.py:90-93: s = a . w_s per region, softmax over the K regions, vhat = sum_k p_k v[b,k,:]. */
+int vqa_attn_fwd(void* stream, int dtype, const void* a, const void* ws, const float* v, int B, int K, int H, int D,
+                 float* p, float* vhat, void* vhat_t);
+int vqa_attn_bwd(void* stream, int dtype, const void* a, const void* ws, const float* v, const float* p,
+                 const float* dvhat, int B, int K, int H, int D, float* dv, void* dpre, float* dws_part);
+/* out[b] = sum_k x[b*K + k] (gradient of the question term broadcast over regions, vqa_model.py:83-87). */
+int vqa_group_sum(void* stream, int dtype, const void* x, int B, int K, int H, float* out, void* out_t);
+/* vqa_model.py:99-101: fv * fq (* dropout mask), and its backward through both ReLUs. */
+int vqa_hadamard_fwd(void* stream, int dtype, const float* fv, const float* fq, const float* mask, long n, void* out);
+int vqa_hadamard_bwd(void* stream, int dtype, const float* dm0, const float* fv, const float* fq, const float* mask,
+                     long n, void* dpv, void* dpq);
+int vqa_relu_bwd(void* stream, int dtype, const float* g, const float* act, const float* mask, long n, void* out);
+int vqa_mask_mul(void* stream, int dtype, const float* x, const float* mask, long n, void* out);
+
+/* ---------------------------------------------------------------- loss, accuracy, optimizer */
+
+/* nn.BCEWithLogitsLoss(reduction='sum') (vqa_model.py:215) and its gradient sigmoid(x) - t in one pass. */
+int vqa_bce_sum(void* stream, const float* logits, const float* target, int B, int C, int ldx, float* dlogits,
+                double* part, float* loss);
+/* vqa_model.py:127-130 without the per-sample host loop: acc[0] = sum_b target[b][argmax_c logits[b][c]]. */
+int vqa_soft_accuracy_sum(void* stream, const float* logits, const float* target, int B, int C, int ldx, float* rows,
+                          float* acc);
+/* nn.utils.clip_grad_norm_(max_norm, 2) + optim.Adamax step (vqa_model.py:259, :218, :266) over one flat f32
+ * parameter / gradient buffer, no host synchronisation; max_norm <= 0 skips the clip. */
+int vqa_clip_adamax(void* stream, float* p, const float* g, float* m, float* u, long n, float max_norm, float lr,
+                    float b1, float b2, float eps, int step, double* part, float* sq, float* coef,
+                    float* total_norm);
+
+/* ---------------------------------------------------------------- hardware-layout probe (tests only) */
+int vqa_probe_tr16(void* stream, const void* in, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQA_HIP_H */

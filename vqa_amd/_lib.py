@@ -57,3 +57,44 @@ def call(name, *args):
         else:
             conv.append(ctypes.c_long(int(a)))   # x86-64: int and long params both read it correctly
     check(fn(*conv), name)
+
+
+def declared_symbols():
+    """Names of every function include/vqa_hip.h declares."""
+    import re
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'vqa_hip.h')
+    with open(hdr) as f:
+        return sorted(set(re.findall(r'^int (vqa_\w+)\(', f.read(), flags=re.M)))
+
+
+# --- optional per-call device timing (bench.py's roofline leg): events on the launching stream around each call
+_PROFILE = None
+
+
+def profile_start():
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_stop():
+    """-> {entry point: [(ms, tag), ...]}"""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, tag, e0, e1 in rec:
+        out.setdefault(name, []).append((e0.elapsed_time(e1), tag))
+    return out
+
+
+_call_raw = call
+
+
+def call(name, *args, tag=None):  # noqa: F811
+    if _PROFILE is None:
+        return _call_raw(name, *args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _call_raw(name, *args)
+    e1.record()
+    _PROFILE.append((name, tag, e0, e1))

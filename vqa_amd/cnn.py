@@ -62,7 +62,14 @@ def pack_weights(w, cin_p, dtype, dgrad):
     return out
 
 
-def conv_fwd(x, wpk, bias, cout, pad, want_stats):
+def _conv_tag(kind, B, OH, OW, cin_real, cout_real, x, y_elems_bytes, w_bytes):
+    """Algorithmic work of one conv launch for bench.py's roofline leg: MACs as the reference writes them
+    (real channel counts), bytes = input read once + output written once + weights."""
+    return dict(kind=kind, flops=2.0 * B * OH * OW * 9 * cin_real * cout_real,
+                bytes=float(x.numel() * x.element_size() + y_elems_bytes + w_bytes))
+
+
+def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd'):
     """x NHWC [B,IH,IW,Cin] -> y [B,OH,OW,Cout] (+ partial BN statistics rows)."""
     B, IH, IW, cin = x.shape
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
@@ -72,7 +79,10 @@ def conv_fwd(x, wpk, bias, cout, pad, want_stats):
     if want_stats:
         rows = B * (-(-OH // R)) * (-(-OW // CW))
         stats = torch.empty(rows, cout, 2, device=x.device, dtype=torch.float32)
-    L.call('vqa_conv3x3_fwd', L.dt(x), x, wpk, y, bias, stats, B, IH, IW, cin, OH, OW, cout, pad, R, CW)
+    cr = cin if cin_real is None else cin_real
+    tag = _conv_tag(kind, B, OH, OW, cr, cout, x,
+                    y.numel() * y.element_size(), wpk.numel() * wpk.element_size())
+    L.call('vqa_conv3x3_fwd', L.dt(x), x, wpk, y, bias, stats, B, IH, IW, cin, OH, OW, cout, pad, R, CW, tag=tag)
     return y, stats
 
 
@@ -87,7 +97,9 @@ def conv_wgrad(x, dy, cin_real, pad):
     G = max(1, min(tiles, 2048 // pairs))
     part = torch.empty(G, cout, 9, cin, device=x.device, dtype=torch.float32)
     dw = torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)
-    L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw, G, B, IH, IW, cin, cin_real, OH, OW, cout, pad, R, CW)
+    tag = _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4)
+    L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw, G, B, IH, IW, cin, cin_real, OH, OW, cout, pad, R, CW,
+           tag=tag)
     return dw
 
 
@@ -110,7 +122,7 @@ def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training):
     mean, invstd) for block_bwd."""
     dev, dtype, cout = x.device, x.dtype, w.shape[0]
     wpk = pack_weights(w, x.shape[3], dtype, dgrad=False)
-    y, stats = conv_fwd(x, wpk, bias, cout, pad, training)
+    y, stats = conv_fwd(x, wpk, bias, cout, pad, training, cin_real=w.shape[1])
     scale = torch.empty(cout, device=dev, dtype=torch.float32)
     shift, mean, invstd = torch.empty_like(scale), torch.empty_like(scale), torch.empty_like(scale)
     if training:
@@ -147,7 +159,7 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx):
     dx = None
     if need_dx:
         wpk = pack_weights(w, x.shape[3], x.dtype, dgrad=True)
-        dx, _ = conv_fwd(dy, wpk, None, x.shape[3], 2 - pad, False)
+        dx, _ = conv_fwd(dy, wpk, None, x.shape[3], 2 - pad, False, kind='dgrad')
     return dx, dw, dbias, dgamma, dbeta
 
 

@@ -1,0 +1,151 @@
+"""Training-step tail and data parallelism for the drop-in model.
+
+* FlatParams   : all parameters of a module re-pointed into ONE fp32 buffer (and all .grad into another), laid
+                 out in reverse execution order (head, GRU, CNN) and cut into buckets.
+* GradBuckets  : data-parallel gradient exchange: each bucket is all-reduced (SUM - the loss is a sum,
+                 reference vqa_model.py:215) asynchronously on RCCL as soon as autograd has produced its last
+                 gradient, so the head/GRU buckets (90 % of the bytes) travel under the CNN backward.
+* FlatAdamax   : nn.utils.clip_grad_norm_(max_norm, L2) + torch.optim.Adamax step (reference vqa_model.py:259,
+                 :218, :266) as one HIP pass over the flat buffers with no host synchronisation.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import ops
+
+
+def _bucket_of(name):
+    if name.startswith('cnn.'):
+        return 2
+    if name.startswith('gru.'):
+        return 1
+    return 0
+
+
+class FlatParams:
+    def __init__(self, module):
+        named = sorted(module.named_parameters(), key=lambda kv: _bucket_of(kv[0]))   # stable: head, gru, cnn
+        dev = named[0][1].device
+        n = sum(p.numel() for _, p in named)
+        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.names, self.params, self.bucket_ranges = [], [], []
+        off, cur, start = 0, None, 0
+        for name, p in named:
+            b = _bucket_of(name)
+            if cur is not None and b != cur:
+                self.bucket_ranges.append((start, off))
+                start = off
+            cur = b
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            self.names.append(name)
+            self.params.append(p)
+            off += k
+        self.bucket_ranges.append((start, off))
+        self.numel = n
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p in self.params:           # keep .grad pointing into the flat buffer (autograd accumulates in place)
+            if p.grad is None or p.grad.data_ptr() < self.grad.data_ptr():
+                raise RuntimeError('parameter .grad was detached from the flat buffer (use zero_grad here)')
+
+
+class GradBuckets:
+    """Bucketed asynchronous gradient all-reduce (SUM) over torch.distributed (backend 'nccl' = RCCL on ROCm,
+    'gloo' in the CPU tests)."""
+
+    def __init__(self, flat: FlatParams, group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.pending, self.handles = [], []
+        self._left = []
+        if self.world > 1:
+            # a bucket is ready when the LAST of its parameters has accumulated its gradient
+            ends = [e for _, e in flat.bucket_ranges]
+            off = 0
+            self._bucket_idx = []
+            for p in flat.params:
+                self._bucket_idx.append(next(i for i, e in enumerate(ends) if off < e))
+                off += p.numel()
+            for i, p in enumerate(flat.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(self._bucket_idx[i]))
+        self.reset()
+
+    def reset(self):
+        self.handles = []
+        counts = [0] * len(self.flat.bucket_ranges)
+        if self.world > 1:
+            for b in self._bucket_idx:
+                counts[b] += 1
+        self._left = counts
+
+    def _make_hook(self, b):
+        def hook(_p):
+            self._left[b] -= 1
+            if self._left[b] == 0:
+                s, e = self.flat.bucket_ranges[b]
+                self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                    async_op=True))
+        return hook
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.reset()
+
+
+class FlatAdamax:
+    def __init__(self, flat: FlatParams, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=0.25):
+        self.flat, self.lr, self.betas, self.eps, self.max_norm = flat, lr, betas, eps, max_norm
+        dev = flat.flat.device
+        self.m = torch.zeros_like(flat.flat)
+        self.u = torch.zeros_like(flat.flat)
+        self.step_count = 0
+        self.part = torch.empty(256, device=dev, dtype=torch.float64)
+        self.sq = torch.zeros(1, device=dev)
+        self.coef = torch.ones(1, device=dev)
+        self.total_norm = torch.zeros(1, device=dev)     # device scalar: read it only when you want to sync
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def step(self):
+        self.step_count += 1
+        f = self.flat
+        L.check(L.lib().vqa_clip_adamax(L.stream(), L.ptr(f.flat), L.ptr(f.grad), L.ptr(self.m), L.ptr(self.u),
+                                        ctypes.c_long(f.numel), ctypes.c_float(self.max_norm or 0.0),
+                                        ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
+                                        ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps),
+                                        ctypes.c_int(self.step_count), L.ptr(self.part), L.ptr(self.sq),
+                                        L.ptr(self.coef), L.ptr(self.total_norm)), 'vqa_clip_adamax')
+
+
+class Trainer:
+    """One reference training step (vqa_model.py:248-266) on the HIP path:
+    zero_grad -> flip -> forward -> sum-BCE -> backward (-> bucketed all-reduce) -> clip 0.25 -> Adamax."""
+
+    def __init__(self, model, lr=2e-3, max_norm=0.25):
+        from .vqa_model import SoftScoreBCELoss
+        self.model = model
+        self.flat = FlatParams(model)
+        self.buckets = GradBuckets(self.flat)
+        self.opt = FlatAdamax(self.flat, lr=lr, max_norm=max_norm)
+        self.criterion = SoftScoreBCELoss()
+
+    def step(self, images, questions, target, flip=True):
+        self.opt.zero_grad()
+        if flip:
+            images = self.model.flip(images)
+        logits = self.model(images, questions)
+        loss = self.criterion(logits, target)
+        loss.backward()
+        self.buckets.wait()
+        self.opt.step()
+        return loss.detach()

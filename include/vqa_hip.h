@@ -74,8 +74,8 @@ int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K, const void
              int accumulate, void* C2, int ldc2);
 /* out[0] = <a, b> (f32 data, f64 accumulation); part = 256 doubles of scratch. */
 int vqa_dot(void* stream, const float* a, const float* b, long n, double* part, float* out);
-/* out[n] = sum_m x[m][n] (bias gradients). */
-int vqa_colsum(void* stream, int dtype, const void* x, int M, int N, int ldx, float* out);
+/* out[n] = sum_m x[m][n] (bias gradients); `slabs` row slabs go through scratch [slabs][N] (NULL if slabs == 1). */
+int vqa_colsum(void* stream, int dtype, const void* x, int M, int N, int ldx, float* out, float* scratch, int slabs);
 /* weight_norm(dim=None) forward (vqa_model.py:59-75): W = v * g / sqrt(sumsq) as a T copy and a transposed T copy
  * (wt may be NULL). */
 int vqa_wn_apply(void* stream, int dtype, const float* v, const float* g, const float* sumsq, int out, int in,

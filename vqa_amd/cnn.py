@@ -94,7 +94,7 @@ def conv_wgrad(x, dy, cin_real, pad):
     tiles = B * (-(-OH // R)) * (-(-OW // CW))
     ck = _ck(cin, x.dtype)
     pairs = (-(-cout // 64)) * (cin // ck)
-    G = max(1, min(tiles, 2048 // pairs))
+    G = max(1, min(tiles, 512 // pairs if pairs <= 512 else 1))
     part = torch.empty(G, cout, 9, cin, device=x.device, dtype=torch.float32)
     dw = torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)
     tag = _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4)

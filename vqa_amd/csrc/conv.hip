@@ -333,15 +333,27 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     }
 }
 
-// dW[co][ci][tap] (torch layout, ci < Cin_real) = sum_g part[g][co][tap][ci]
-__global__ void conv3x3_wgrad_reduce(const float* part, float* dw, int G, int Cout, int Cin, int Cin_real) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// dW[co][ci][tap] (torch layout, ci < Cin_real) = sum_g part[g][co][tap][ci], fixed summation order.
+// 256 threads = OPB outputs x TPO partial-lanes; TPO grows as the output count shrinks so that small layers
+// (2304 outputs, hundreds of partials) still fill the chip.
+template <int TPO>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce(const float* part, float* dw, int G, int Cout, int Cin,
+                                                            int Cin_real) {
+    constexpr int OPB = 256 / TPO;
+    __shared__ float red[256];
     const int n = Cout * 9 * Cin;
-    if (i >= n) return;
-    const int ci = i % Cin, tp = (i / Cin) % 9, co = i / (9 * Cin);
+    const int ol = threadIdx.x % OPB, gl = threadIdx.x / OPB;
+    const int i = blockIdx.x * OPB + ol;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += part[(long)g * n + i];
-    if (ci < Cin_real) dw[((long)co * Cin_real + ci) * 9 + tp] = s;
+    if (i < n)
+        for (int g = gl; g < G; g += TPO) s += part[(long)g * n + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (gl == 0 && i < n) {
+        for (int k = 1; k < TPO; ++k) s += red[k * OPB + ol];
+        const int ci = i % Cin, tp = (i / Cin) % 9, co = i / (9 * Cin);
+        if (ci < Cin_real) dw[((long)co * Cin_real + ci) * 9 + tp] = s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- packing
@@ -370,17 +382,23 @@ __global__ void conv_pack(const float* w, T* out, int Cout, int Cin, int CinP, i
     out[i] = from_f32<T>(v);
 }
 
-// images [B][C][H][W] (f32 / f16 / bf16) -> NHWC [B][H][W][CP] in T, channels >= C zero
+// images [B][C][H][W] (f32 / f16 / bf16) -> NHWC [B][H][W][CP] in T, channels >= C zero.  One thread per pixel:
+// coalesced plane reads (consecutive lanes = consecutive pixels), 16-byte stores of the CP-channel vector.
 template <typename TI, typename T>
 __global__ void nchw_to_nhwc(const TI* in, T* out, int B, int C, int H, int W, int CP) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long n = (long)B * H * W;
-    if (i >= n) return;
-    const long hw = (long)H * W;
-    const long b = i / hw, p = i % hw;
-    for (int c = 0; c < CP; ++c) {
-        float v = c < C ? to_f32(in[(b * C + c) * hw + p]) : 0.f;
-        out[i * CP + c] = from_f32<T>(v);
+    constexpr int VEC = 16 / sizeof(T);
+    const long n = (long)B * H * W, hw = (long)H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / hw, p = i % hw;
+        for (int c0 = 0; c0 < CP; c0 += VEC) {
+            T v[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int c = c0 + j;
+                v[j] = from_f32<T>(c < C ? to_f32(in[(b * C + c) * hw + p]) : 0.f);
+            }
+            *reinterpret_cast<uint4*>(out + i * CP + c0) = *reinterpret_cast<uint4*>(v);
+        }
     }
 }
 
@@ -437,7 +455,12 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     }
     if (status != VQA_OK) return status;
     const int n = Cout * 9 * Cin;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((n + 255) / 256), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
+    if (n >= 262144 || G <= 4)
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<4>, dim3((n + 63) / 64), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
+    else if (n >= 32768 || G <= 16)
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<16>, dim3((n + 15) / 16), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
+    else
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<64>, dim3((n + 3) / 4), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
     CHECK_LAUNCH();
     return VQA_OK;
 }
@@ -462,7 +485,9 @@ extern "C" int vqa_conv_pack(void* stream, int dtype, const float* w, void* out,
 extern "C" int vqa_nchw_to_nhwc(void* stream, int in_dtype, int out_dtype, const void* in, void* out, int B, int C,
                                 int H, int W, int CP) {
     const long n = (long)B * H * W;
-    dim3 grid((unsigned)((n + 255) / 256));
+    if (CP % 8) return VQA_ERR_ARG;
+    long gb = (n + 255) / 256;
+    dim3 grid((unsigned)(gb > 8192 ? 8192 : gb));
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define GO(TI, TO) hipLaunchKernelGGL((nchw_to_nhwc<TI, TO>), grid, dim3(256), 0, s, static_cast<const TI*>(in), \
                                       static_cast<TO*>(out), B, C, H, W, CP)

@@ -29,18 +29,21 @@ __global__ void dot_final(const double* part, int n, float* out) {
     if (threadIdx.x == 0) out[0] = (float)s;
 }
 
-// out[n] (+)= sum_m X[m][n]
+// out[n] = sum_m X[m][n].  Block = 64 columns x 4 row-lanes; grid.y row slabs are combined in a second launch.
 template <typename T>
-__global__ void colsum(const T* x, int M, int N, int ldx, float* out) {
+__global__ void colsum(const T* x, int M, int N, int ldx, float* out, int rows_per_slab) {
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int part = threadIdx.x >> 6;   // 4 row groups
+    const int part = threadIdx.x >> 6;   // 4 row lanes
+    const int m0 = blockIdx.y * rows_per_slab;
+    const int m1 = m0 + rows_per_slab < M ? m0 + rows_per_slab : M;
     float s = 0.f;
     if (n < N)
-        for (int m = part; m < M; m += 4) s += to_f32(x[(long)m * ldx + n]);
+        for (int m = m0 + part; m < m1; m += 4) s += to_f32(x[(long)m * ldx + n]);
     __shared__ float r[4][64];
     r[part][threadIdx.x & 63] = s;
     __syncthreads();
-    if (part == 0 && n < N) out[n] = r[0][threadIdx.x] + r[1][threadIdx.x] + r[2][threadIdx.x] + r[3][threadIdx.x];
+    if (part == 0 && n < N)
+        out[(long)blockIdx.y * N + n] = r[0][threadIdx.x] + r[1][threadIdx.x] + r[2][threadIdx.x] + r[3][threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------- weight norm
@@ -345,10 +348,18 @@ extern "C" int vqa_dot(void* stream, const float* a, const float* b, long n, dou
     return VQA_OK;
 }
 
-extern "C" int vqa_colsum(void* stream, int dtype, const void* x, int M, int N, int ldx, float* out) {
-    dim3 grid((N + 63) / 64);
-    BY_T(dtype, hipLaunchKernelGGL(colsum<bf16>, grid, dim3(256), 0, ST, (const bf16*)x, M, N, ldx, out),
-         hipLaunchKernelGGL(colsum<float>, grid, dim3(256), 0, ST, (const float*)x, M, N, ldx, out));
+// out[n] = sum_m x[m][n].  `slabs` (>= 1) row slabs are summed independently into scratch [slabs][N] and combined
+// in fixed order; scratch may be NULL when slabs == 1.
+extern "C" int vqa_colsum(void* stream, int dtype, const void* x, int M, int N, int ldx, float* out, float* scratch,
+                          int slabs) {
+    if (slabs < 1 || (slabs > 1 && !scratch)) return VQA_ERR_ARG;
+    const int rps = (M + slabs - 1) / slabs;
+    dim3 grid((N + 63) / 64, slabs);
+    float* dst = slabs > 1 ? scratch : out;
+    BY_T(dtype, hipLaunchKernelGGL(colsum<bf16>, grid, dim3(256), 0, ST, (const bf16*)x, M, N, ldx, dst, rps),
+         hipLaunchKernelGGL(colsum<float>, grid, dim3(256), 0, ST, (const float*)x, M, N, ldx, dst, rps));
+    if (slabs > 1)
+        hipLaunchKernelGGL(colsum<float>, dim3((N + 63) / 64, 1), dim3(256), 0, ST, scratch, slabs, N, N, out, slabs);
     CHECK_LAUNCH();
     return VQA_OK;
 }

@@ -55,7 +55,9 @@ def colsum(x, M=None, N=None):
     M = x.shape[0] if M is None else M
     N = x.shape[1] if N is None else N
     out = torch.empty(N, device=x.device, dtype=torch.float32)
-    L.call('vqa_colsum', L.dt(x), x, M, N, x.stride(0), out)
+    slabs = max(1, min(64, M // 64))
+    scr = torch.empty(slabs, N, device=x.device, dtype=torch.float32) if slabs > 1 else None
+    L.call('vqa_colsum', L.dt(x), x, M, N, x.stride(0), out, scr, slabs)
     return out
 
 

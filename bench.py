@@ -112,6 +112,9 @@ def roofline_leg(trainer, batch):
     else:
         out.update(achieved=round(tfl, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s',
                    frac=round(tfl / MFMA_BF16_PEAK_TFLOPS, 4))
+    out['per_launch'] = [f"{name}[{tag['kind']}] {tag['shape']:>18s} {ms:7.3f} ms {tag['flops'] / ms / 1e9:8.1f} TF/s "
+                         f"{tag['bytes'] / ms / 1e6:8.1f} GB/s"
+                         for name, recs in prof.items() for ms, tag in recs if tag]
     breakdown = {k: round(v['ms'], 3) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]['ms'])[:12]}
     return out, breakdown, sum(totals.values())
 
@@ -200,6 +203,9 @@ def main():
         result['device_ms_in_kernels'] = round(dev_ms, 3)
         if args.breakdown:
             print(json.dumps(breakdown, indent=1), file=sys.stderr)
+            for ln in roof.pop('per_launch'):
+                print(ln, file=sys.stderr)
+        roof.pop('per_launch', None)
         if not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.hidden, classes, vocab)
     if rank == 0:

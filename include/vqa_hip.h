@@ -39,7 +39,7 @@ int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked,
 int vqa_conv3x3_stat_rows(int B, int OH, int OW, int R, int CW);
 
 /* Conv2d weight gradient (autograd of cnn.py:23-40): dw [Cout][Cin_real][3][3] f32 = sum over pixels of dy (x) x.
- * `part` is a [G][Cout][9][Cin] f32 workspace (G workgroup groups, summed in fixed order). */
+ * `part` is a [4*G][Cout][9][Cin] f32 workspace (G workgroup groups x up to 4 pixel slices, summed in fixed order). */
 int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const void* dy, float* part, float* dw, int G, int B,
                       int IH, int IW, int Cin, int Cin_real, int OH, int OW, int Cout, int pad, int R, int CW);
 

@@ -65,7 +65,7 @@ def pack_weights(w, cin_p, dtype, dgrad):
 def _conv_tag(kind, B, OH, OW, cin_real, cout_real, x, y_elems_bytes, w_bytes):
     """Algorithmic work of one conv launch for bench.py's roofline leg: MACs as the reference writes them
     (real channel counts), bytes = input read once + output written once + weights."""
-    return dict(kind=kind, flops=2.0 * B * OH * OW * 9 * cin_real * cout_real,
+    return dict(kind=kind, shape=f'{OH}x{OW} {cin_real}->{cout_real}', flops=2.0 * B * OH * OW * 9 * cin_real * cout_real,
                 bytes=float(x.numel() * x.element_size() + y_elems_bytes + w_bytes))
 
 
@@ -94,8 +94,11 @@ def conv_wgrad(x, dy, cin_real, pad):
     tiles = B * (-(-OH // R)) * (-(-OW // CW))
     ck = _ck(cin, x.dtype)
     pairs = (-(-cout // 64)) * (cin // ck)
-    G = max(1, min(tiles, 512 // pairs if pairs <= 512 else 1))
-    part = torch.empty(G, cout, 9, cin, device=x.device, dtype=torch.float32)
+    esz = x.element_size()
+    lds = (R + 2) * (CW + 2) * (ck * esz + 16) + (-(-R * CW // (64 // esz)) * (64 // esz)) * (64 * esz + 16)
+    per_cu = max(1, min(6, (150 * 1024) // lds))
+    G = max(1, min(tiles, (256 * per_cu) // pairs if pairs <= 256 * per_cu else 1))
+    part = torch.empty(4 * G, cout, 9, cin, device=x.device, dtype=torch.float32)
     dw = torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)
     tag = _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4)
     L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw, G, B, IH, IW, cin, cin_real, OH, OW, cout, pad, R, CW,

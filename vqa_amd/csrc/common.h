@@ -54,6 +54,15 @@ template <> struct Mma<bf16> {
     }
 };
 
+// i / d for 0 <= i < 2^22 and a runtime d, with inv = 1.0f / d from the host: a float multiply and two
+// corrections instead of the ~40-instruction integer division sequence.
+__device__ __forceinline__ int fastdiv(int i, int d, float inv) {
+    int q = (int)((float)i * inv);
+    q -= (q * d > i);
+    q += ((q + 1) * d <= i);
+    return q;
+}
+
 // Sum over the 16 lanes that share lane>>4 (the lanes holding different D columns of the same rows).
 __device__ __forceinline__ float sum16(float v) {
     v += __shfl_xor(v, 1);

@@ -26,6 +26,7 @@ struct ConvArgs {
     float* stats;       // [tiles*B][Cout][2] partial (sum, sumsq) or null
     int B, IH, IW, Cin, OH, OW, Cout, pad;
     int R, CW, tiles_x, tiles_y;
+    float inv_cw, inv_pw, inv_tx;
 };
 
 template <typename T, int CK> struct ConvCfg {
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int tile = blockIdx.x, b = blockIdx.y, co0 = blockIdx.z * NB;
-    const int ty = tile / a.tiles_x, tx = tile % a.tiles_x;
+    const int ty = fastdiv(tile, a.tiles_x, a.inv_tx), tx = tile - ty * a.tiles_x;
     const int oy0 = ty * a.R, ox0 = tx * a.CW;
     const int MT = a.R * a.CW;
     const T* x = static_cast<const T*>(a.x);
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm(ConvArgs a) {
         const int m = (wave * 4 + f) * 16 + r;
         int pr = 0, pc = 0;
         bool ok = m < MT;
-        if (ok) { pr = m / a.CW; pc = m % a.CW; }
+        if (ok) { pr = fastdiv(m, a.CW, a.inv_cw); pc = m - pr * a.CW; }
         ok = ok && (oy0 + pr < a.OH) && (ox0 + pc < a.OW);
         pbase[f] = (pr * PW + pc) * PXB;
         opix[f] = ok ? ((b * a.OH + oy0 + pr) * a.OW + ox0 + pc) : -1;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm(ConvArgs a) {
         // ---- stage the input patch (zero outside the image) and the weight slab
         for (int i = tid; i < PPIX * VPP; i += 256) {
             const int px = i / VPP, vv = i % VPP;
-            const int py = px / PW, pxx = px % PW;
+            const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
             const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
@@ -200,10 +201,14 @@ struct WgradArgs {
     float* part;     // [G][Cout][9][Cin] partial sums
     int B, IH, IW, Cin, OH, OW, Cout, pad;
     int R, CW, tiles_x, tiles_y;
+    int nwk;  // waves along the pixel (reduction) axis: 4 / min(4, Cout/16)
+    float inv_cw, inv_pw, inv_tx, inv_tiles;
 };
 
 // One workgroup: NB = 64 output channels x CK input channels x 9 taps, looping over pixel tiles
-// t = blockIdx.x, blockIdx.x + gridDim.x, ...  Wave w owns the 16 output channels [16w, 16w+16).
+// t = blockIdx.x, blockIdx.x + gridDim.x, ...  The 4 waves split as (4/nwk output-channel fragments) x (nwk slices
+// of the pixel reduction), so layers with 16 or 32 output channels still use every wave; each pixel slice writes
+// its own partial slab.
 template <typename T, int CK>
 __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     constexpr int VEC = Mma<T>::VEC, KC = 4 * VEC;
@@ -222,6 +227,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     const int nco = (a.Cout + NB - 1) / NB;
     const int co0 = (blockIdx.y % nco) * NB, ci0 = (blockIdx.y / nco) * CK;
     const int cow = a.Cout - co0 < NB ? a.Cout - co0 : NB;  // valid output channels of this block
+    const int nwco = 4 / a.nwk;
+    const int wco = wave % nwco, wk = wave / nwco;
     const T* x = static_cast<const T*>(a.x);
     const T* dy = static_cast<const T*>(a.dy);
 
@@ -233,22 +240,25 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
 
     const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        const int b = t / tiles, tl = t % tiles;
-        const int oy0 = (tl / a.tiles_x) * a.R, ox0 = (tl % a.tiles_x) * a.CW;
+        const int b = fastdiv(t, tiles, a.inv_tiles), tl = t - b * tiles;
+        const int tyy = fastdiv(tl, a.tiles_x, a.inv_tx);
+        const int oy0 = tyy * a.R, ox0 = (tl - tyy * a.tiles_x) * a.CW;
         for (int i = tid; i < PPIX * VPP; i += 256) {
             const int px = i / VPP, vv = i % VPP;
-            const int py = px / PW, pxx = px % PW;
+            const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
             const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
                 v = *reinterpret_cast<const uint4*>(x + ((long)(b * a.IH + iy) * a.IW + ix) * a.Cin + ci0 + vv * VEC);
             *reinterpret_cast<uint4*>(patch + px * PXB + vv * 16) = v;
         }
-        for (int i = tid; i < MTP * DVP; i += 256) {
-            const int m = i / DVP, vv = i % DVP;
+        const int dvp = cow / VEC;   // 16-byte vectors per pixel that hold real channels (cow = 16, 32 or 64)
+        const int dsh = dvp == 8 ? 3 : (dvp == 4 ? 2 : (dvp == 2 ? 1 : (dvp == 16 ? 4 : 0)));
+        for (int i = tid; i < (MTP << dsh); i += 256) {
+            const int m = i >> dsh, vv = i & (dvp - 1);
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (m < MT && vv * VEC < cow) {
-                const int pr = m / a.CW, pc = m % a.CW;
+            if (m < MT) {
+                const int pr = fastdiv(m, a.CW, a.inv_cw), pc = m - pr * a.CW;
                 if (oy0 + pr < a.OH && ox0 + pc < a.OW)
                     v = *reinterpret_cast<const uint4*>(dy + ((long)(b * a.OH + oy0 + pr) * a.OW + ox0 + pc) * a.Cout +
                                                         co0 + vv * VEC);
@@ -256,8 +266,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
             *reinterpret_cast<uint4*>(dyl + m * DYB + vv * 16) = v;
         }
         __syncthreads();
-        if (wave * 16 < cow) {
-            for (int ks = 0; ks < MTP; ks += KC) {
+        if (wco * 16 < cow) {
+            for (int ks = wk * KC; ks < MTP; ks += a.nwk * KC) {
                 if constexpr (sizeof(T) == 2) {
                     // bf16: lane i = 4*rq + p of a 16-lane group supplies the address of k-row rq, channels 4p..4p+3;
                     // it receives channel i of 4 k-rows.  Two reads = the 8 k (pixels) of lane group q.
@@ -269,12 +279,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             int m = ks + q * 8 + h * 4 + rq;
-                            const unsigned char* ad = dyl + m * DYB + (wave * 16 + 4 * p) * 2;
+                            const unsigned char* ad = dyl + m * DYB + (wco * 16 + 4 * p) * 2;
                             bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                                 (__attribute__((address_space(3))) bf16x4*)(ad));
                             if (h == 0) lo = v; else hi = v;
                             if (m >= MT) m = 0;
-                            poff[h] = ((m / a.CW) * PW + (m % a.CW)) * PXB + 4 * p * 2;
+                            const int pr = fastdiv(m, a.CW, a.inv_cw);
+                            poff[h] = (pr * PW + (m - pr * a.CW)) * PXB + 4 * p * 2;
                         }
                         bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         fa = __builtin_bit_cast(uint4, f);
@@ -299,9 +310,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         int m = ks + 4 * j + q;
-                        fa[j] = *reinterpret_cast<const float*>(dyl + m * DYB + (wave * 16 + r) * 4);
+                        fa[j] = *reinterpret_cast<const float*>(dyl + m * DYB + (wco * 16 + r) * 4);
                         if (m >= MT) m = 0;
-                        poff[j] = ((m / a.CW) * PW + (m % a.CW)) * PXB + r * 4;
+                        const int pr = fastdiv(m, a.CW, a.inv_cw);
+                        poff[j] = (pr * PW + (m - pr * a.CW)) * PXB + r * 4;
                     }
 #pragma unroll
                     for (int tp = 0; tp < 9; ++tp) {
@@ -320,15 +332,16 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
         __syncthreads();
     }
     // D rows = co (4q+e), D cols = ci (r)
-    if (wave * 16 < cow) {
+    if (wco * 16 < cow) {
+        const long slab = (long)blockIdx.x * a.nwk + wk;
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
             for (int c = 0; c < CF; ++c)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int co = co0 + wave * 16 + q * 4 + e, ci = ci0 + c * 16 + r;
-                    a.part[(((long)blockIdx.x * a.Cout + co) * 9 + tp) * a.Cin + ci] = acc[tp][c][e];
+                    const int co = co0 + wco * 16 + q * 4 + e, ci = ci0 + c * 16 + r;
+                    a.part[((slab * a.Cout + co) * 9 + tp) * a.Cin + ci] = acc[tp][c][e];
                 }
     }
 }
@@ -411,7 +424,7 @@ extern "C" int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const voi
         (R + 2) * (CW + 2) > 640)
         return VQA_ERR_ARG;
     ConvArgs a{x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, (OW + CW - 1) / CW,
-               (OH + R - 1) / R};
+               (OH + R - 1) / R, 1.0f / CW, 1.0f / (CW + 2), 1.0f / ((OW + CW - 1) / CW)};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == VQA_BF16) {
         if (Cin % 32 == 0) return dispatch_nb<bf16, 32>(s, a);
@@ -431,7 +444,10 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
                                  int G, int B, int IH, int IW, int Cin, int Cin_real, int OH, int OW, int Cout,
                                  int pad, int R, int CW) {
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || G < 1) return VQA_ERR_ARG;
-    WgradArgs a{x, dy, part, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, (OW + CW - 1) / CW, (OH + R - 1) / R};
+    const int tx_ = (OW + CW - 1) / CW, ty_ = (OH + R - 1) / R;
+    const int nwk = Cout >= 64 ? 1 : (Cout >= 32 ? 2 : 4);
+    WgradArgs a{x, dy, part, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_, nwk,
+                1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_)};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int MT = R * CW, PPIX = (R + 2) * (CW + 2);
     int status = VQA_ERR_ARG;
@@ -455,12 +471,12 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     }
     if (status != VQA_OK) return status;
     const int n = Cout * 9 * Cin;
-    if (n >= 262144 || G <= 4)
-        hipLaunchKernelGGL(conv3x3_wgrad_reduce<4>, dim3((n + 63) / 64), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
-    else if (n >= 32768 || G <= 16)
-        hipLaunchKernelGGL(conv3x3_wgrad_reduce<16>, dim3((n + 15) / 16), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
+    if (n >= 262144 || G * nwk <= 4)
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<4>, dim3((n + 63) / 64), dim3(256), 0, s, part, dw, G * nwk, Cout, Cin, Cin_real);
+    else if (n >= 32768 || G * nwk <= 16)
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<16>, dim3((n + 15) / 16), dim3(256), 0, s, part, dw, G * nwk, Cout, Cin, Cin_real);
     else
-        hipLaunchKernelGGL(conv3x3_wgrad_reduce<64>, dim3((n + 3) / 4), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<64>, dim3((n + 3) / 4), dim3(256), 0, s, part, dw, G * nwk, Cout, Cin, Cin_real);
     CHECK_LAUNCH();
     return VQA_OK;
 }

@@ -90,13 +90,13 @@ def conv_wgrad(x, dy, cin_real, pad):
     B, IH, IW, cin = x.shape
     _, OH, OW, cout = dy.shape
     mt = 256 if x.dtype == torch.bfloat16 else 128
-    R, CW = pick_tile(OH, OW, mt, 640 if mt == 256 else 320)
+    R, CW = pick_tile(OH, OW, mt, 512 if mt == 256 else 320)
     tiles = B * (-(-OH // R)) * (-(-OW // CW))
     ck = _ck(cin, x.dtype)
     pairs = (-(-cout // 64)) * (cin // ck)
     esz = x.element_size()
     lds = (R + 2) * (CW + 2) * (ck * esz + 16) + (-(-R * CW // (64 // esz)) * (64 // esz)) * (64 * esz + 16)
-    per_cu = max(1, min(6, (150 * 1024) // lds))
+    per_cu = max(1, min(3 if ck == 16 else 2, (160 * 1024) // lds))
     G = max(1, min(tiles, (256 * per_cu) // pairs if pairs <= 256 * per_cu else 1))
     part = torch.empty(4 * G, cout, 9, cin, device=x.device, dtype=torch.float32)
     dw = torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     constexpr int VEC = Mma<T>::VEC, KC = 4 * VEC;
     constexpr int PXB = CK * (int)sizeof(T) + PADB;
     constexpr int NB = 64, DYB = NB * (int)sizeof(T) + PADB;
-    constexpr int VPP = CK * (int)sizeof(T) / 16, DVP = NB * (int)sizeof(T) / 16;
+    constexpr int VPP = CK * (int)sizeof(T) / 16;
     constexpr int CF = CK / 16;  // input-channel fragments
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int PW = a.CW + 2, PPIX = (a.R + 2) * PW, MT = a.R * a.CW;
@@ -239,33 +239,61 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
         for (int c = 0; c < CF; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    // Software pipeline over pixel tiles: the global loads of tile t+1 are issued into registers before the MFMA
+    // loop of tile t and written to LDS after it, so HBM latency hides under compute even at 1-2 blocks per CU.
+    constexpr int PMAX = sizeof(T) == 2 ? 512 : 320;               // host bound on (R+2)*(CW+2)
+    constexpr int NPV = (PMAX * VPP + 255) / 256, NDV = 8;         // 16-byte vectors per thread: patch, dy tile
+    uint4 pv[NPV], dv[NDV];
+    const int dvp = cow / VEC;   // 16-byte vectors per pixel that hold real channels (cow = 16, 32 or 64)
+    const int dsh = dvp == 16 ? 4 : (dvp == 8 ? 3 : (dvp == 4 ? 2 : (dvp == 2 ? 1 : 0)));
+    auto fetch = [&](int t) {
         const int b = fastdiv(t, tiles, a.inv_tiles), tl = t - b * tiles;
         const int tyy = fastdiv(tl, a.tiles_x, a.inv_tx);
         const int oy0 = tyy * a.R, ox0 = (tl - tyy * a.tiles_x) * a.CW;
-        for (int i = tid; i < PPIX * VPP; i += 256) {
-            const int px = i / VPP, vv = i % VPP;
-            const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
-            const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
+#pragma unroll
+        for (int j = 0; j < NPV; ++j) {
+            const int i = tid + j * 256;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
-                v = *reinterpret_cast<const uint4*>(x + ((long)(b * a.IH + iy) * a.IW + ix) * a.Cin + ci0 + vv * VEC);
-            *reinterpret_cast<uint4*>(patch + px * PXB + vv * 16) = v;
+            if (i < PPIX * VPP) {
+                const int px = i / VPP, vv = i % VPP;
+                const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
+                const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
+                if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
+                    v = *reinterpret_cast<const uint4*>(x + ((long)(b * a.IH + iy) * a.IW + ix) * a.Cin + ci0 + vv * VEC);
+            }
+            pv[j] = v;
         }
-        const int dvp = cow / VEC;   // 16-byte vectors per pixel that hold real channels (cow = 16, 32 or 64)
-        const int dsh = dvp == 8 ? 3 : (dvp == 4 ? 2 : (dvp == 2 ? 1 : (dvp == 16 ? 4 : 0)));
-        for (int i = tid; i < (MTP << dsh); i += 256) {
-            const int m = i >> dsh, vv = i & (dvp - 1);
+#pragma unroll
+        for (int j = 0; j < NDV; ++j) {
+            const int i = tid + j * 256;
             uint4 v = make_uint4(0, 0, 0, 0);
+            const int m = i >> dsh, vv = i & (dvp - 1);
             if (m < MT) {
                 const int pr = fastdiv(m, a.CW, a.inv_cw), pc = m - pr * a.CW;
                 if (oy0 + pr < a.OH && ox0 + pc < a.OW)
                     v = *reinterpret_cast<const uint4*>(dy + ((long)(b * a.OH + oy0 + pr) * a.OW + ox0 + pc) * a.Cout +
                                                         co0 + vv * VEC);
             }
-            *reinterpret_cast<uint4*>(dyl + m * DYB + vv * 16) = v;
+            dv[j] = v;
         }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPV; ++j) {
+            const int i = tid + j * 256;
+            if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + (i / VPP) * PXB + (i % VPP) * 16) = pv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NDV; ++j) {
+            const int i = tid + j * 256;
+            if (i < (MTP << dsh)) *reinterpret_cast<uint4*>(dyl + (i >> dsh) * DYB + (i & (dvp - 1)) * 16) = dv[j];
+        }
+    };
+    if ((int)blockIdx.x < total) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        stash();
         __syncthreads();
+        if (t + (int)gridDim.x < total) fetch(t + gridDim.x);
         if (wco * 16 < cow) {
             for (int ks = wk * KC; ks < MTP; ks += a.nwk * KC) {
                 if constexpr (sizeof(T) == 2) {
@@ -462,11 +490,11 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
         return hipGetLastError() == hipSuccess ? VQA_OK : VQA_ERR_LAUNCH;
     };
     if (dtype == VQA_BF16) {
-        if (MT > 256) return VQA_ERR_ARG;
+        if (MT > 256 || PPIX > 512) return VQA_ERR_ARG;
         if (Cin % 32 == 0) status = go(conv3x3_wgrad<bf16, 32>, 32, 2);
         else if (Cin == 16) status = go(conv3x3_wgrad<bf16, 16>, 16, 2);
     } else if (dtype == VQA_F32) {
-        if (MT > 128) return VQA_ERR_ARG;
+        if (MT > 128 || PPIX > 320) return VQA_ERR_ARG;
         if (Cin % 16 == 0) status = go(conv3x3_wgrad<float, 16>, 16, 4);
     }
     if (status != VQA_OK) return status;

@@ -68,10 +68,11 @@ int vqa_bn_bwd_finalize(void* stream, const float* part, int rows, int C, double
 
 /* MFMA GEMM with fused epilogue.  trans = 0: C[M,N] = A[M,K] * B[N,K]^T (nn.Linear forward, input gradients with a
  * pre-transposed weight).  trans = 1: C[M,N] = A[K,M]^T * B[K,N] (weight gradients).  Epilogue: + bias[n],
- * + rowadd[m / rowadd_group][n], ReLU (act = 1), C += (accumulate = 1), optional bf16 copy C2. */
+ * + rowadd[m / rowadd_group][n], ReLU (act = 1), C += (accumulate = 1), optional bf16 copy C2.
+ * splits > 1: split-K over grid.z with raw partial sums in splitk_ws [splits][M][N] f32, summed in slice order. */
 int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
              void* C, int ldc, int c_dtype, const float* bias, const float* rowadd, int rowadd_group, int act,
-             int accumulate, void* C2, int ldc2);
+             int accumulate, void* C2, int ldc2, float* splitk_ws, int splits);
 /* out[0] = <a, b> (f32 data, f64 accumulation); part = 256 doubles of scratch. */
 int vqa_dot(void* stream, const float* a, const float* b, long n, double* part, float* out);
 /* out[n] = sum_m x[m][n] (bias gradients); `slabs` row slabs go through scratch [slabs][N] (NULL if slabs == 1). */

@@ -5,7 +5,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _gemm(A, B, trans, out_dtype=torch.float32, bias=None, rowadd=None, group=1, act=0, acc=None):
+def _gemm(A, B, trans, out_dtype=torch.float32, bias=None, rowadd=None, group=1, act=0, acc=None, splits=1):
     from vqa_amd import _lib as L
     if trans:
         K, M = A.shape
@@ -14,8 +14,9 @@ def _gemm(A, B, trans, out_dtype=torch.float32, bias=None, rowadd=None, group=1,
         M, K = A.shape
         N = B.shape[0]
     C = acc.clone() if acc is not None else torch.empty(M, N, device='cuda', dtype=out_dtype)
+    ws = torch.empty(splits, M, N, device='cuda') if splits > 1 else None
     L.call('vqa_gemm', L.dt(A), int(trans), M, N, K, A, A.stride(0), B, B.stride(0), C, C.stride(0), L.dt(C),
-           bias, rowadd, group, act, int(acc is not None), None, 0)
+           bias, rowadd, group, act, int(acc is not None), None, 0, ws, splits)
     return C
 
 
@@ -52,6 +53,10 @@ def test_gemm_epilogue():
     ref = torch.relu(A @ B.t() + bias + rowadd.repeat_interleave(G, 0)) + acc
     C = _gemm(A, B, 0, bias=bias, rowadd=rowadd, group=G, act=1, acc=acc)
     assert float((C - ref).norm() / ref.norm()) < 1e-5
+    C = _gemm(A, B, 0, bias=bias, rowadd=rowadd, group=G, act=1, acc=acc, splits=3)     # split-K, same epilogue
+    assert float((C - ref).norm() / ref.norm()) < 1e-5
+    Ct = _gemm(A.t().contiguous(), B.t().contiguous(), 1, splits=2)
+    assert float((Ct - A @ B.t()).norm() / (A @ B.t()).norm()) < 1e-5
     Cb = _gemm(A.bfloat16(), B.bfloat16(), 0, out_dtype=torch.bfloat16)
     refb = A.bfloat16().float() @ B.bfloat16().float().t()
     assert float((Cb.float() - refb).norm() / refb.norm()) < 5e-3

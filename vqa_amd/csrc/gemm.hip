@@ -21,6 +21,7 @@ struct GemmArgs {
     const float* rowadd; int rowadd_group;
     int act, accumulate;
     bf16* C2; int ldc2;
+    float* ws; int kper;   // split-K: grid.z slices of `kper` k each write raw sums to ws[z][M][N]
 };
 
 template <typename T>
@@ -61,7 +62,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < g.K; k0 += KC) {
+    const int kbeg = g.ws ? blockIdx.z * g.kper : 0;
+    const int kend = g.ws ? (kbeg + g.kper < g.K ? kbeg + g.kper : g.K) : g.K;
+    for (int k0 = kbeg; k0 < kend; k0 += KC) {
         if (!TN) {
             const int row = tid >> 2, vc = tid & 3;
             uint4 va = load_row_chunk<T>(A, m0 + row, g.lda, k0 + vc * VEC, g.K, m0 + row < g.M);
@@ -97,6 +100,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
+    if (g.ws) {   // split-K slice: raw partial sums, epilogue applied by gemm_splitk_reduce
+        float* W = g.ws + (long)blockIdx.z * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wm * 32 + i * 16 + r;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + wn * 32 + j * 16 + q * 4 + e;
+                    if (n < g.N) W[(long)m * g.N + n] = acc[i][j][e];
+                }
+        }
+        return;
+    }
     TC* C = static_cast<TC*>(g.C);
     const bool vec_ok = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                         (g.C2 == nullptr || g.ldc2 % 4 == 0);
@@ -136,11 +155,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// C = epilogue(sum_z ws[z]) in fixed slice order
+template <typename TC>
+__global__ void gemm_splitk_reduce(GemmArgs g, int splits) {
+    TC* C = static_cast<TC*>(g.C);
+    const long total = (long)g.M * g.N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = i % g.N;
+        const long m = i / g.N;
+        float x = 0.f;
+        for (int z = 0; z < splits; ++z) x += g.ws[(long)z * total + i];
+        if (g.bias) x += g.bias[n];
+        if (g.rowadd) x += g.rowadd[(m / g.rowadd_group) * g.N + n];
+        if (g.act == 1) x = fmaxf(x, 0.f);
+        if (g.accumulate) x += to_f32(C[m * g.ldc + n]);
+        C[m * g.ldc + n] = from_f32<TC>(x);
+        if (g.C2) g.C2[m * g.ldc2 + n] = (bf16)x;
+    }
+}
+
 template <typename T, typename TC>
-int launch(hipStream_t s, int trans, const GemmArgs& g) {
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
+int launch(hipStream_t s, int trans, const GemmArgs& g, int splits) {
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
     if (trans) hipLaunchKernelGGL((gemm_kernel<T, TC, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_kernel<T, TC, false>), grid, dim3(256), 0, s, g);
+    if (g.ws) {
+        long blocks = ((long)g.M * g.N + 255) / 256;
+        hipLaunchKernelGGL(gemm_splitk_reduce<TC>, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, g,
+                           splits);
+    }
     CHECK_LAUNCH();
     return VQA_OK;
 }
@@ -149,14 +192,19 @@ int launch(hipStream_t s, int trans, const GemmArgs& g) {
 
 extern "C" int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K, const void* A, int lda,
                         const void* B, int ldb, void* C, int ldc, int c_dtype, const float* bias,
-                        const float* rowadd, int rowadd_group, int act, int accumulate, void* C2, int ldc2) {
+                        const float* rowadd, int rowadd_group, int act, int accumulate, void* C2, int ldc2,
+                        float* splitk_ws, int splits) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return VQA_ERR_ARG;
     if (rowadd && rowadd_group <= 0) return VQA_ERR_ARG;
+    if (splits < 1 || (splits > 1 && !splitk_ws)) return VQA_ERR_ARG;
+    const int kc = dtype == VQA_BF16 ? 32 : 16;
+    const int kper = ((K + splits - 1) / splits + kc - 1) / kc * kc;
+    splits = splits > 1 ? (K + kper - 1) / kper : 1;
     GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, bias, rowadd, rowadd_group, act, accumulate,
-               static_cast<bf16*>(C2), ldc2};
+               static_cast<bf16*>(C2), ldc2, splits > 1 ? splitk_ws : nullptr, kper};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == VQA_F32 && c_dtype == VQA_F32) return launch<float, float>(s, trans, g);
-    if (dtype == VQA_BF16 && c_dtype == VQA_F32) return launch<bf16, float>(s, trans, g);
-    if (dtype == VQA_BF16 && c_dtype == VQA_BF16) return launch<bf16, bf16>(s, trans, g);
+    if (dtype == VQA_F32 && c_dtype == VQA_F32) return launch<float, float>(s, trans, g, splits);
+    if (dtype == VQA_BF16 && c_dtype == VQA_F32) return launch<bf16, float>(s, trans, g, splits);
+    if (dtype == VQA_BF16 && c_dtype == VQA_BF16) return launch<bf16, bf16>(s, trans, g, splits);
     return VQA_ERR_ARG;
 }

@@ -28,8 +28,16 @@ def gemm(A, B, trans=False, M=None, N=None, K=None, out=None, out_dtype=torch.fl
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=out_dtype)
     assert out.stride(1) == 1
+    # split-K when the output grid alone cannot fill 256 CUs and the reduction is long
+    blocks = -(-M // 64) * -(-N // 64)
+    splits = 1
+    if blocks < 384 and K >= 512:
+        splits = max(1, min(16, 768 // blocks, K // 256))
+    ws = torch.empty(splits, M, N, device=A.device, dtype=torch.float32) if splits > 1 else None
+    tag = dict(kind='tn' if trans else 'nt', shape=f'{M}x{N}x{K}', flops=2.0 * M * N * K,
+               bytes=float((M * K + N * K) * A.element_size() + M * N * out.element_size()))
     L.call('vqa_gemm', L.dt(A), int(trans), M, N, K, A, A.stride(0), B, B.stride(0), out, out.stride(0), L.dt(out),
-           bias, rowadd, group, act, int(accumulate), c2, c2.stride(0) if c2 is not None else 0)
+           bias, rowadd, group, act, int(accumulate), c2, c2.stride(0) if c2 is not None else 0, ws, splits, tag=tag)
     return out
 
 

@@ -39,16 +39,16 @@ int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked,
 int vqa_conv3x3_stat_rows(int B, int OH, int OW, int R, int CW);
 
 /* Conv2d weight gradient (autograd of cnn.py:23-40): dw [Cout][Cin_real][3][3] f32 = sum over pixels of dy (x) x.
- * `part` is a [4*G][Cout][9][Cin] f32 workspace (G workgroup groups x up to 4 pixel slices, summed in fixed order). */
+ * `part` is a [G][Cout][9][Cin] f32 workspace (one partial slab per workgroup group, summed in fixed order). */
 int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const void* dy, float* part, float* dw, int G, int B,
                       int IH, int IW, int Cin, int Cin_real, int OH, int OW, int Cout, int pad, int R, int CW);
 
 /* nn.BatchNorm2d training statistics (cnn.py:23-40; eps 1e-5, momentum 0.1): from the conv partials to mean,
  * invstd, scale = gamma*invstd, shift = beta - mean*scale; running_mean / running_var updated in place
- * (unbiased variance); running_* may be NULL. */
+ * (unbiased variance); running_* may be NULL.  slab = scratch of 32*C*2 doubles (two-stage fixed-order sum). */
 int vqa_bn_finalize(void* stream, const float* part, int rows, int C, double count, const float* gamma,
                     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                    float* mean, float* invstd, float* scale, float* shift);
+                    float* mean, float* invstd, float* scale, float* shift, double* slab);
 /* eval-mode BatchNorm2d: scale / shift from the running statistics. */
 int vqa_bn_eval_coeffs(void* stream, int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift);

@@ -98,7 +98,7 @@ def conv_wgrad(x, dy, cin_real, pad):
     lds = (R + 2) * (CW + 2) * (ck * esz + 16) + (-(-R * CW // (64 // esz)) * (64 // esz)) * (64 * esz + 16)
     per_cu = max(1, min(3 if ck == 16 else 2, (160 * 1024) // lds))
     G = max(1, min(tiles, (256 * per_cu) // pairs if pairs <= 256 * per_cu else 1))
-    part = torch.empty(4 * G, cout, 9, cin, device=x.device, dtype=torch.float32)
+    part = torch.empty(G, cout, 9, cin, device=x.device, dtype=torch.float32)
     dw = torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)
     tag = _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4)
     L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw, G, B, IH, IW, cin, cin_real, OH, OW, cout, pad, R, CW,
@@ -133,7 +133,9 @@ def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training):
         L.check(L.lib().vqa_bn_finalize(L.stream(), L.ptr(stats), stats.shape[0], cout, L.ctypes.c_double(count),
                                         L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv),
                                         L.ctypes.c_float(BN_MOMENTUM), L.ctypes.c_float(BN_EPS), L.ptr(mean),
-                                        L.ptr(invstd), L.ptr(scale), L.ptr(shift)), 'vqa_bn_finalize')
+                                        L.ptr(invstd), L.ptr(scale), L.ptr(shift),
+                                        L.ptr(torch.empty(32 * cout * 2, device=dev, dtype=torch.float64))),
+                'vqa_bn_finalize')
     else:
         L.call('vqa_bn_eval_coeffs', cout, gamma, beta, rm, rv, BN_EPS, scale, shift)
     a = bn_act_pool(y, scale, shift, pool)

@@ -27,12 +27,11 @@ template <typename T> struct Vec {
     }
 };
 
-__global__ void bn_finalize(const float* part, int rows, int C, double count, const float* gamma, const float* beta,
-                            float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                            float* invstd, float* scale, float* shift) {
-    const int c = blockIdx.x;
+// Stage 1 of the statistics: grid (C, S) - slab s sums rows s, s+S, ... of the conv partials for one channel.
+__global__ void bn_stats_slab(const float* part, int rows, int C, double* slab /* [S][C][2] */) {
+    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
     double s1 = 0.0, s2 = 0.0;
-    for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+    for (int i = s + threadIdx.x * S; i < rows; i += blockDim.x * S) {
         s1 += (double)part[((long)i * C + c) * 2];
         s2 += (double)part[((long)i * C + c) * 2 + 1];
     }
@@ -42,21 +41,33 @@ __global__ void bn_finalize(const float* part, int rows, int C, double count, co
     if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        s1 = r1[0] + r1[1] + r1[2] + r1[3];
-        s2 = r2[0] + r2[1] + r2[2] + r2[3];
-        const double m = s1 / count;
-        double var = s2 / count - m * m;
-        if (var < 0.0) var = 0.0;
-        const float is = (float)(1.0 / sqrt(var + (double)eps));
-        mean[c] = (float)m;
-        invstd[c] = is;
-        const float sc = gamma[c] * is;
-        scale[c] = sc;
-        shift[c] = beta[c] - (float)m * sc;
-        if (running_mean) {
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * count / (count - 1.0));
-        }
+        slab[((long)s * C + c) * 2] = r1[0] + r1[1] + r1[2] + r1[3];
+        slab[((long)s * C + c) * 2 + 1] = r2[0] + r2[1] + r2[2] + r2[3];
+    }
+}
+// Stage 2: one thread per channel combines the S slabs in fixed order and produces the BN coefficients.
+__global__ void bn_finalize(const double* slab, int S, int C, double count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                            float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < S; ++s) {
+        s1 += slab[((long)s * C + c) * 2];
+        s2 += slab[((long)s * C + c) * 2 + 1];
+    }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m;
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)m * sc;
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * count / (count - 1.0));
     }
 }
 
@@ -261,11 +272,15 @@ int grid_for(long items, int per_block) {
 
 }  // namespace
 
+// slab: scratch of VQA_BN_SLABS * C * 2 doubles
 extern "C" int vqa_bn_finalize(void* stream, const float* part, int rows, int C, double count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                               float* mean, float* invstd, float* scale, float* shift) {
-    hipLaunchKernelGGL(bn_finalize, dim3(C), dim3(256), 0, static_cast<hipStream_t>(stream), part, rows, C, count,
-                       gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+                               float* mean, float* invstd, float* scale, float* shift, double* slab) {
+    constexpr int S = 32;   // VQA_BN_SLABS
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_stats_slab, dim3(C, S), dim3(256), 0, st, part, rows, C, slab);
+    hipLaunchKernelGGL(bn_finalize, dim3((C + 63) / 64), dim3(64), 0, st, slab, S, C, count, gamma, beta, running_mean,
+                       running_var, momentum, eps, mean, invstd, scale, shift);
     CHECK_LAUNCH();
     return VQA_OK;
 }

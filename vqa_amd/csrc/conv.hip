@@ -207,8 +207,8 @@ struct WgradArgs {
 
 // One workgroup: NB = 64 output channels x CK input channels x 9 taps, looping over pixel tiles
 // t = blockIdx.x, blockIdx.x + gridDim.x, ...  The 4 waves split as (4/nwk output-channel fragments) x (nwk slices
-// of the pixel reduction), so layers with 16 or 32 output channels still use every wave; each pixel slice writes
-// its own partial slab.
+// of the pixel reduction), so layers with 16 or 32 output channels still use every wave; the slices are combined
+// through LDS at the end and each workgroup writes one partial slab.
 template <typename T, int CK>
 __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     constexpr int VEC = Mma<T>::VEC, KC = 4 * VEC;
@@ -359,9 +359,30 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
         }
         __syncthreads();
     }
+    // combine the pixel slices of the block in LDS (fixed order), then one partial slab per workgroup
+    if (a.nwk > 1) {
+        float* red = reinterpret_cast<float*>(smem);   // staging LDS is free after the loop's last barrier
+        if (wk > 0 && wco * 16 < cow) {
+            float* dst = red + ((long)((wk - 1) * nwco + wco) * 9 * CF) * 256 + lane * 4;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                for (int c = 0; c < CF; ++c)
+                    *reinterpret_cast<f32x4*>(dst + (tp * CF + c) * 256) = acc[tp][c];
+        }
+        __syncthreads();
+        if (wk == 0 && wco * 16 < cow) {
+            for (int k = 1; k < a.nwk; ++k) {
+                const float* src = red + ((long)((k - 1) * nwco + wco) * 9 * CF) * 256 + lane * 4;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                    for (int c = 0; c < CF; ++c) acc[tp][c] += *reinterpret_cast<const f32x4*>(src + (tp * CF + c) * 256);
+            }
+        }
+    }
     // D rows = co (4q+e), D cols = ci (r)
-    if (wco * 16 < cow) {
-        const long slab = (long)blockIdx.x * a.nwk + wk;
+    if (wk == 0 && wco * 16 < cow) {
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
@@ -369,7 +390,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int co = co0 + wco * 16 + q * 4 + e, ci = ci0 + c * 16 + r;
-                    a.part[((slab * a.Cout + co) * 9 + tp) * a.Cin + ci] = acc[tp][c][e];
+                    a.part[(((long)blockIdx.x * a.Cout + co) * 9 + tp) * a.Cin + ci] = acc[tp][c][e];
                 }
     }
 }
@@ -483,6 +504,8 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
         const int KC = 64 / esz;
         const int MTP = (MT + KC - 1) / KC * KC;
         size_t lds = (size_t)(PPIX * (CK * esz + PADB) + 15) / 16 * 16 + (size_t)MTP * (64 * esz + PADB);
+        const size_t red = (size_t)(nwk - 1) * (4 / nwk) * 9 * (CK / 16) * 1024;   // cross-slice combine buffer
+        if (lds < red) lds = red;
         if (lds > 160 * 1024) return VQA_ERR_ARG;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         dim3 grid(G, ((Cout + 63) / 64) * (Cin / CK));
@@ -499,12 +522,12 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     }
     if (status != VQA_OK) return status;
     const int n = Cout * 9 * Cin;
-    if (n >= 262144 || G * nwk <= 4)
-        hipLaunchKernelGGL(conv3x3_wgrad_reduce<4>, dim3((n + 63) / 64), dim3(256), 0, s, part, dw, G * nwk, Cout, Cin, Cin_real);
-    else if (n >= 32768 || G * nwk <= 16)
-        hipLaunchKernelGGL(conv3x3_wgrad_reduce<16>, dim3((n + 15) / 16), dim3(256), 0, s, part, dw, G * nwk, Cout, Cin, Cin_real);
+    if (n >= 262144 || G <= 4)
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<4>, dim3((n + 63) / 64), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
+    else if (n >= 32768 || G <= 16)
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<16>, dim3((n + 15) / 16), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
     else
-        hipLaunchKernelGGL(conv3x3_wgrad_reduce<64>, dim3((n + 3) / 4), dim3(256), 0, s, part, dw, G * nwk, Cout, Cin, Cin_real);
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<64>, dim3((n + 3) / 4), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
     CHECK_LAUNCH();
     return VQA_OK;
 }

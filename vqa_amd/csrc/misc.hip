@@ -14,8 +14,17 @@ template <typename T> __device__ __forceinline__ float ld(const T* p, long i) { 
 // out[0] = sum_i a[i]*b[i]   (two launches: partials in double, then a fixed-order final sum)
 __global__ void dot_partial(const float* a, const float* b, long n, double* part) {
     double s = 0.0;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        s += (double)a[i] * (double)b[i];
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+    if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) {
+        const long n4 = n >> 2;
+        for (long i = tid; i < n4; i += nth) {
+            const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+            s += (double)(x.x * y.x + x.y * y.y) + (double)(x.z * y.z + x.w * y.w);
+        }
+        for (long i = (n4 << 2) + tid; i < n; i += nth) s += (double)a[i] * (double)b[i];
+    } else {
+        for (long i = tid; i < n; i += nth) s += (double)a[i] * (double)b[i];
+    }
     __shared__ double r[4];
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = s;

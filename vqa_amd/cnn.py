@@ -95,7 +95,8 @@ def conv_wgrad(x, dy, cin_real, pad):
     ck = _ck(cin, x.dtype)
     pairs = (-(-cout // 64)) * (cin // ck)
     esz = x.element_size()
-    lds = (R + 2) * (CW + 2) * (ck * esz + 16) + (-(-R * CW // (64 // esz)) * (64 // esz)) * (64 * esz + 16)
+    pxb = 32 if ck * esz == 32 else ck * esz + 32
+    lds = (R + 2) * (CW + 2) * pxb + (-(-R * CW // (64 // esz)) * (64 // esz)) * (64 * esz + 32)
     per_cu = max(1, min(3 if ck == 16 else 2, (160 * 1024) // lds))
     G = max(1, min(tiles, (256 * per_cu) // pairs if pairs <= 256 * per_cu else 1))
     part = torch.empty(G, cout, 9, cin, device=x.device, dtype=torch.float32)

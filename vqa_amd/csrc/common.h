@@ -64,11 +64,15 @@ __device__ __forceinline__ int fastdiv(int i, int d, float inv) {
 }
 
 // Sum over the 16 lanes that share lane>>4 (the lanes holding different D columns of the same rows).
+// DPP row operations (a DPP row = 16 lanes = exactly one lane>>4 group): 4 VALU ops, no LDS permute traffic.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float sum16(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {

@@ -16,7 +16,11 @@
 
 namespace {
 
-constexpr int PADB = 16;  // LDS row padding (bytes)
+// LDS strides chosen so that the ds_read_b128 fragment reads (lane = 16*q + r reads 16 bytes at r*stride + 16*q) and
+// the ds_read_b64_tr_b16 reads are bank-conflict-free on gfx950: in 16-byte slots the stride must be 2 (mod 4) for
+// b128 (brute-forced over the hardware's lane groups), and a multiple of 32 bytes with an odd quotient for tr_b16.
+__host__ __device__ constexpr int pix_stride(int data_bytes) { return data_bytes == 32 ? 32 : data_bytes + 32; }
+__host__ __device__ constexpr int row_stride(int data_bytes) { return data_bytes + 32; }   // 576->608, 320->352
 
 struct ConvArgs {
     const void* x;      // [B][IH][IW][Cin]
@@ -34,8 +38,8 @@ template <typename T, int CK> struct ConvCfg {
     static constexpr int KC = 4 * VEC;                       // k per MFMA chunk
     static constexpr int KP = (9 * CK + KC - 1) / KC * KC;   // padded k per channel chunk
     static constexpr int NS = KP / KC;                       // chunks per channel chunk
-    static constexpr int PXB = CK * (int)sizeof(T) + PADB;   // LDS bytes per patch pixel
-    static constexpr int WROWB = KP * (int)sizeof(T) + PADB; // LDS bytes per weight row
+    static constexpr int PXB = pix_stride(CK * (int)sizeof(T));   // LDS bytes per patch pixel
+    static constexpr int WROWB = row_stride(KP * (int)sizeof(T)); // LDS bytes per weight row
     static constexpr int VPP = CK * (int)sizeof(T) / 16;     // 16-byte vectors per patch pixel
 };
 
@@ -212,8 +216,8 @@ struct WgradArgs {
 template <typename T, int CK>
 __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     constexpr int VEC = Mma<T>::VEC, KC = 4 * VEC;
-    constexpr int PXB = CK * (int)sizeof(T) + PADB;
-    constexpr int NB = 64, DYB = NB * (int)sizeof(T) + PADB;
+    constexpr int PXB = pix_stride(CK * (int)sizeof(T));
+    constexpr int NB = 64, DYB = NB * (int)sizeof(T) + 32;
     constexpr int VPP = CK * (int)sizeof(T) / 16;
     constexpr int CF = CK / 16;  // input-channel fragments
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -503,7 +507,7 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     auto go = [&](auto kern, int CK, int esz) {
         const int KC = 64 / esz;
         const int MTP = (MT + KC - 1) / KC * KC;
-        size_t lds = (size_t)(PPIX * (CK * esz + PADB) + 15) / 16 * 16 + (size_t)MTP * (64 * esz + PADB);
+        size_t lds = (size_t)(PPIX * pix_stride(CK * esz) + 15) / 16 * 16 + (size_t)MTP * (64 * esz + 32);
         const size_t red = (size_t)(nwk - 1) * (4 / nwk) * 9 * (CK / 16) * 1024;   // cross-slice combine buffer
         if (lds < red) lds = red;
         if (lds > 160 * 1024) return VQA_ERR_ARG;

@@ -10,7 +10,8 @@
 namespace {
 
 constexpr int BM = 64, BN = 64;
-constexpr int ROWB = 80;  // LDS row: 64 bytes of k + 16 pad (bank spread for ds_read_b128)
+constexpr int ROWB = 96;  // LDS row: 64 bytes of k + 32 pad: stride of 6 sixteen-byte slots is conflict-free for the
+                          // ds_read_b128 fragment reads (lane 16q+r reads slot 6r+q; brute-forced over the lane groups)
 
 struct GemmArgs {
     int M, N, K;

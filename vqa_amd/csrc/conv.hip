@@ -310,7 +310,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
                         bf16x4 lo, hi;
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            int m = ks + q * 8 + h * 4 + rq;
+                            // k -> pixel map of the chunk: lane group q, element 4h+e  <->  pixel ks + 16h + 4q + e, so one
+                            // read instruction's 32-lane half touches 8 CONSECUTIVE pixels (bank-conflict-free strides)
+                            int m = ks + h * 16 + q * 4 + rq;
                             const unsigned char* ad = dyl + m * DYB + (wco * 16 + 4 * p) * 2;
                             bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                                 (__attribute__((address_space(3))) bf16x4*)(ad));

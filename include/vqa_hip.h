@@ -101,6 +101,17 @@ int vqa_gru_gate_fwd(void* stream, int dtype, const float* gi, const float* gh, 
 int vqa_gru_gate_bwd(void* stream, int dtype, const float* dh, const float* save, const float* hprev, int B, int H,
                      void* dgi, void* dgh, float* dhprev);
 
+/* The whole nn.GRU recurrence (gru.py:104) in ONE persistent launch: each workgroup keeps its 48 x H slice of W_hh
+ * (bf16) in LDS for all T steps, gates fused in registers, one device-wide barrier per step (bounded spin; flags[1]
+ * != 0 afterwards means a barrier timed out).  bf16 only, H % 256 == 0, 48*(2H+32) <= 160 KiB; otherwise returns 1 and
+ * the caller uses vqa_gemm + vqa_gru_gate_fwd per step.  gi [T][B][3H] f32, h_f / h_t [T+1][B][H] (slot 0 = zeros),
+ * save [T][B][4H], flags = 2 unsigned of scratch. */
+int vqa_gru_fwd_persistent(void* stream, const float* gi, const void* w, int ldw, const float* b_hh, float* h_f,
+                           void* h_t, float* save, int B, int T, int H, unsigned* flags);
+/* BPTT of the same recurrence in one launch: wt = W_hh^T bf16 [H][ldw]; outputs dgi, dgh bf16 [T][B][3H]. */
+int vqa_gru_bwd_persistent(void* stream, const void* wt, int ldw, const float* h_f, const float* save,
+                           const float* dh_last, void* dgi, void* dgh, int B, int T, int H, unsigned* flags);
+
 /* ---------------------------------------------------------------- attention / fusion head (vqa_model.py:83-103) */
 
 /* vqa_model.py:90-93: s = a . w_s per region, softmax over the K regions, vhat = sum_k p_k v[b,k,:]. */

@@ -45,6 +45,17 @@ class _GruParams(nn.Module):
         self.bias_hh_l0 = mk(3 * hidden_size)
 
 
+import os
+# One-launch recurrence (bf16, H % 256 == 0, 48*H*2 bytes of W_hh per workgroup in LDS).  Off by default: the GRU
+# runs on a side stream under the CNN, where the per-step launches fill idle CUs while a persistent grid that spins
+# on its device-wide barrier holds CUs and LDS away from the conv kernels (measured 8.20 vs 7.89 ms/step).
+USE_PERSISTENT = os.environ.get('VQA_GRU_PERSISTENT', '0') != '0'
+
+
+def _persistent_ok(dtype, H):
+    return USE_PERSISTENT and dtype == torch.bfloat16 and H % 256 == 0 and 48 * (2 * H + 32) <= 160 * 1024
+
+
 class _GruFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, dtype, emb, w_ih, w_hh, b_ih, b_hh):
@@ -61,11 +72,15 @@ class _GruFunction(torch.autograd.Function):
         h_f = torch.zeros(T + 1, B, H, device=dev, dtype=torch.float32)   # h_{-1} = 0, h_0 .. h_{T-1}
         h_t = torch.zeros(T + 1, B, H, device=dev, dtype=dtype)
         save = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
-        gh = torch.empty(B, 3 * H, device=dev, dtype=torch.float32)
-        for t in range(T):
-            ops.gemm(h_t[t], whh, out=gh, bias=b_hh)
-            L.call('vqa_gru_gate_fwd', L.dt(x), gi[t * B:(t + 1) * B], gh, h_f[t], B, H, h_f[t + 1], h_t[t + 1],
-                   save[t])
+        if _persistent_ok(dtype, H):
+            flags = torch.empty(2, device=dev, dtype=torch.int32)
+            L.call('vqa_gru_fwd_persistent', gi, whh, whh.stride(0), b_hh, h_f, h_t, save, B, T, H, flags)
+        else:
+            gh = torch.empty(B, 3 * H, device=dev, dtype=torch.float32)
+            for t in range(T):
+                ops.gemm(h_t[t], whh, out=gh, bias=b_hh)
+                L.call('vqa_gru_gate_fwd', L.dt(x), gi[t * B:(t + 1) * B], gh, h_f[t], B, H, h_f[t + 1], h_t[t + 1],
+                       save[t])
         ctx.save_for_backward(q, x, h_f, h_t, save, w_ih, w_hh, emb)
         ctx.dtype = dtype
         return h_f[T].clone()
@@ -83,13 +98,17 @@ class _GruFunction(torch.autograd.Function):
         dgi = torch.empty(T * B, 3 * H, device=dev, dtype=dtype)
         dgh = torch.empty(T * B, 3 * H, device=dev, dtype=dtype)
         dh = dh_last.contiguous().float()
-        for t in range(T - 1, -1, -1):
-            dprev = torch.empty(B, H, device=dev, dtype=torch.float32)
-            L.call('vqa_gru_gate_bwd', L.dt(x), dh, save[t], h_f[t], B, H, dgi[t * B:(t + 1) * B],
-                   dgh[t * B:(t + 1) * B], dprev)
-            if t > 0:
-                ops.gemm(dgh[t * B:(t + 1) * B], whh_T, out=dprev, accumulate=True)   # += dgh_t @ W_hh
-            dh = dprev
+        if _persistent_ok(dtype, H) and 16 * (6 * H + 32) <= 160 * 1024 and B <= 256 * max(1, 256 // (H // 16)):
+            flags = torch.empty(2, device=dev, dtype=torch.int32)
+            L.call('vqa_gru_bwd_persistent', whh_T, whh_T.stride(0), h_f, save, dh, dgi, dgh, B, T, H, flags)
+        else:
+            for t in range(T - 1, -1, -1):
+                dprev = torch.empty(B, H, device=dev, dtype=torch.float32)
+                L.call('vqa_gru_gate_bwd', L.dt(x), dh, save[t], h_f[t], B, H, dgi[t * B:(t + 1) * B],
+                       dgh[t * B:(t + 1) * B], dprev)
+                if t > 0:
+                    ops.gemm(dgh[t * B:(t + 1) * B], whh_T, out=dprev, accumulate=True)   # += dgh_t @ W_hh
+                dh = dprev
         hprev = h_t[:T].reshape(T * B, H)
         dw_hh = ops.gemm(dgh, hprev, trans=True)                 # [3H, H]
         dw_ih = ops.gemm(dgi, x[:, :E], trans=True)              # [3H, E]

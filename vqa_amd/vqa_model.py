@@ -20,6 +20,20 @@ from . import _lib as L
 from . import cnn, gru, ops
 
 
+import os
+
+_SIDE = {}
+SIDE_STREAM = os.environ.get('VQA_SIDE_STREAM', '1') != '0'
+
+
+def _side_stream(device):
+    """One extra HIP stream per device (module scope: nothing native is stored on the nn.Module)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 class RandomHorizontalFlip(nn.Module):
     """torchvision.transforms.RandomHorizontalFlip as the reference uses it (vqa_model.py:41, :250): one draw
     flips the whole batch along the width axis."""
@@ -195,8 +209,21 @@ class VQA(nn.Module):
     def forward(self, images_batch, questions_batch):
         if not images_batch.is_cuda:
             raise L.VqaHipError('vqa_amd.VQA runs on an MI355X only: there is no CPU fallback for the hot path')
-        images_representation = self.cnn(images_batch)              # [B, k, d]
-        questions_representation = self.gru(questions_batch)        # [B, H]
+        # The question encoder (28 small latency-bound launches per direction) is independent of the image
+        # encoder: it runs on a side HIP stream, under the CNN kernels.  Autograd replays each backward on its
+        # forward's stream, so the GRU's BPTT overlaps the CNN backward the same way.
+        if SIDE_STREAM:
+            cur = torch.cuda.current_stream()
+            side = _side_stream(images_batch.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                questions_representation = self.gru(questions_batch)    # [B, H]
+            images_representation = self.cnn(images_batch)              # [B, k, d]
+            cur.wait_stream(side)
+            questions_representation.record_stream(cur)
+        else:
+            images_representation = self.cnn(images_batch)
+            questions_representation = self.gru(questions_batch)
         dtype = torch.bfloat16 if self.precision == 'bf16' else torch.float32
         B = images_batch.shape[0]
         masks = (self._dropout_mask(B, images_batch.device), self._dropout_mask(B, images_batch.device))

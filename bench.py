@@ -80,33 +80,46 @@ def cpu_baseline(hidden, classes, vocab, seconds=20.0):
                       f'{len(times)} steps after 2 warm-up'}
 
 
+# C-ABI entry point -> the device kernel (template family) that does its work
+KERNEL_OF = {'vqa_conv3x3_fwd': 'conv3x3_igemm', 'vqa_conv3x3_wgrad': 'conv3x3_wgrad', 'vqa_gemm': 'gemm_bf16',
+             'vqa_bn_bwd': 'bn_bwd', 'vqa_bn_act_pool_fwd': 'bn_act_pool_fwd'}
+
+
 def roofline_leg(trainer, batch):
-    """One extra, instrumented step: HIP events around every C-ABI call on the launching stream; picks the kernel
-    with the largest total device time and prices it against its binding roofline."""
+    """One extra, instrumented step: HIP events around every C-ABI call on the launching stream (question encoder
+    kept on the main stream for this step, so no launch is timed under a concurrent kernel); picks the device kernel
+    with the largest total time (conv3x3_igemm serves the forward conv AND the data gradient) and prices the sum of
+    its launches against the roofline that binds that sum."""
     from vqa_amd import _lib as L
-    L.profile_start()
-    trainer.step(*batch)
-    prof = L.profile_stop()
+    from vqa_amd import vqa_model as VM
+    side, VM.SIDE_STREAM = VM.SIDE_STREAM, False
+    try:
+        trainer.step(*batch)
+        L.profile_start()
+        trainer.step(*batch)
+        prof = L.profile_stop()
+    finally:
+        VM.SIDE_STREAM = side
     totals = {k: sum(ms for ms, _ in v) for k, v in prof.items()}
-    # conv3x3_fwd serves both the forward conv and the data gradient; keep them apart
-    rows = {}
+    rows, fam = {}, {}
     for name, recs in prof.items():
         for ms, tag in recs:
-            key = name if not tag else f"{name}[{tag['kind']}]"
-            r = rows.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
-            r['ms'] += ms
-            r['n'] += 1
-            if tag:
-                r['flops'] += tag['flops']
-                r['bytes'] += tag['bytes']
-    dom = max((k for k in rows if rows[k]['bytes'] > 0), key=lambda k: rows[k]['ms'])
-    r = rows[dom]
+            for table, key in ((rows, name if not tag else f"{name}[{tag['kind']}]"), (fam, KERNEL_OF.get(name, name))):
+                r = table.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
+                r['ms'] += ms
+                r['n'] += 1
+                if tag:
+                    r['flops'] += tag['flops']
+                    r['bytes'] += tag['bytes']
+    dom = max((k for k in fam if fam[k]['bytes'] > 0), key=lambda k: fam[k]['ms'])
+    r = fam[dom]
     gbs = r['bytes'] / (r['ms'] * 1e-3) / 1e9
     tfl = r['flops'] / (r['ms'] * 1e-3) / 1e12
-    intensity = r['flops'] / r['bytes']
-    bound = 'mfma' if intensity > MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9) else 'hbm'
+    # binding roofline of the launches taken together: the one that needs more time at its peak
+    bound = 'mfma' if r['flops'] / (MFMA_BF16_PEAK_TFLOPS * 1e12) > r['bytes'] / (HBM_PEAK_GBS * 1e9) else 'hbm'
     out = {'kernel': dom, 'bound': bound, 'launches_per_step': r['n'], 'avg_launch_ms': round(r['ms'] / r['n'], 4),
-           'traffic': None, 'tflops': round(tfl, 2), 'gbs': round(gbs, 1)}
+           'traffic': None, 'tflops': round(tfl, 2), 'gbs': round(gbs, 1),
+           'algorithmic_bytes_per_launch': round(r['bytes'] / r['n']), 'kernel_ms_per_step': round(r['ms'], 3)}
     if bound == 'hbm':
         out.update(achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
     else:
@@ -115,7 +128,7 @@ def roofline_leg(trainer, batch):
     out['per_launch'] = [f"{name}[{tag['kind']}] {tag['shape']:>18s} {ms:7.3f} ms {tag['flops'] / ms / 1e9:8.1f} TF/s "
                          f"{tag['bytes'] / ms / 1e6:8.1f} GB/s"
                          for name, recs in prof.items() for ms, tag in recs if tag]
-    breakdown = {k: round(v['ms'], 3) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]['ms'])[:12]}
+    breakdown = {k: round(v['ms'], 3) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]['ms'])[:14]}
     return out, breakdown, sum(totals.values())
 
 
@@ -197,8 +210,9 @@ def main():
                    'weights': 'module-default init, seed 42', 'final_loss': round(final_loss, 3)},
         'step_tflops_algorithmic': round(value * GFLOP_PER_SAMPLE_TRAIN / 1e3, 2),
     }
-    if rank == 0 and world == 1:
-        roof, breakdown, dev_ms = roofline_leg(trainer, batch)
+    # every rank runs the instrumented step (it all-reduces like any other); rank 0 reports its own timings
+    roof, breakdown, dev_ms = roofline_leg(trainer, batch)
+    if rank == 0:
         result['roofline'] = roof
         result['device_ms_in_kernels'] = round(dev_ms, 3)
         if args.breakdown:
@@ -206,7 +220,7 @@ def main():
             for ln in roof.pop('per_launch'):
                 print(ln, file=sys.stderr)
         roof.pop('per_launch', None)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             result['cpu_baseline'] = cpu_baseline(args.hidden, classes, vocab)
     if rank == 0:
         print(json.dumps(result), flush=True)

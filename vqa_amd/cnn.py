@@ -110,7 +110,8 @@ def conv_wgrad(x, dy, cin_real, pad):
 def bn_act_pool(y, scale, shift, pool):
     B, H, W, C = y.shape
     a = torch.empty(B, H // 2 if pool else H, W // 2 if pool else W, C, device=y.device, dtype=y.dtype)
-    L.call('vqa_bn_act_pool_fwd', L.dt(y), y, a, scale, shift, B, H, W, C, pool)
+    tag = dict(kind='fwd', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((y.numel() + a.numel()) * y.element_size()))
+    L.call('vqa_bn_act_pool_fwd', L.dt(y), y, a, scale, shift, B, H, W, C, pool, tag=tag)
     return a
 
 
@@ -154,10 +155,14 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx):
     dgamma = torch.empty(C, device=dev, dtype=torch.float32)
     dbeta, c1, c2 = torch.empty_like(dgamma), torch.empty_like(dgamma), torch.empty_like(dgamma)
     dy = torch.empty_like(y)
-    L.call('vqa_bn_bwd', L.dt(y), 0, y, d, None, scale, shift, mean, invstd, None, None, part, B, H, W, C, pool)
+    es = y.element_size()
+    tag = dict(kind='reduce', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((y.numel() + d.numel()) * es))
+    L.call('vqa_bn_bwd', L.dt(y), 0, y, d, None, scale, shift, mean, invstd, None, None, part, B, H, W, C, pool,
+           tag=tag)
     L.check(L.lib().vqa_bn_bwd_finalize(L.stream(), L.ptr(part), rows, C, L.ctypes.c_double(count), L.ptr(dgamma),
                                         L.ptr(dbeta), L.ptr(c1), L.ptr(c2)), 'vqa_bn_bwd_finalize')
-    L.call('vqa_bn_bwd', L.dt(y), 1, y, d, dy, scale, shift, mean, invstd, c1, c2, None, B, H, W, C, pool)
+    tag = dict(kind='apply', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((2 * y.numel() + d.numel()) * es))
+    L.call('vqa_bn_bwd', L.dt(y), 1, y, d, dy, scale, shift, mean, invstd, c1, c2, None, B, H, W, C, pool, tag=tag)
     dw = conv_wgrad(x, dy, cin_real, pad)
     # the conv bias feeds a training-mode BatchNorm: its gradient is identically zero (the reference produces
     # rounding noise ~1e-7 of the weight-gradient scale here)

@@ -43,6 +43,36 @@ __device__ __forceinline__ uint4 load_row_chunk(const T* base, long row, int ld,
     return v;
 }
 
+
+// bias / row-broadcast add / ReLU / accumulate, then a 4-wide store of C (and the optional bf16 copy C2)
+template <typename TC>
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, TC* C, int m, int n, const f32x4& a, bool vec_ok) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = a[e];
+        const int ne = n + e;
+        if (ne < g.N) {
+            if (g.bias) x += g.bias[ne];
+            if (g.rowadd) x += g.rowadd[(long)(m / g.rowadd_group) * g.N + ne];
+            if (g.act == 1) x = fmaxf(x, 0.f);
+            if (g.accumulate) x += to_f32(C[(long)m * g.ldc + ne]);
+        }
+        v[e] = x;
+    }
+    if (vec_ok && n + 3 < g.N) {
+        store_vec4<TC>(C + (long)m * g.ldc + n, v);
+        if (g.C2) store_vec4<bf16>(g.C2 + (long)m * g.ldc2 + n, v);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < g.N) {
+                C[(long)m * g.ldc + n + e] = from_f32<TC>(v[e]);
+                if (g.C2) g.C2[(long)m * g.ldc2 + n + e] = (bf16)v[e];
+            }
+    }
+}
+
 template <typename T, typename TC, bool TN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     constexpr int VEC = Mma<T>::VEC;
@@ -128,30 +158,158 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 32 + j * 16 + q * 4;
             if (n >= g.N) continue;
-            float v[4];
+            epilogue_store<TC>(g, C, m, n, acc[i][j], vec_ok);
+        }
+    }
+}
+
+
+// ---- bf16 pipelined kernel -------------------------------------------------------------------------------------------
+// Same contract as gemm_kernel, bf16 operands only.  Differences: BK = 64 or 128 k per stage, two LDS buffers and a
+// register-prefetch pipeline (global loads of stage s+1 are in flight during the MFMAs of stage s; ONE barrier per
+// stage), 64x64 or 128x128 tiles, and the TN mode keeps the source's k-major rows in LDS and builds fragments with
+// the transposing read ds_read_b64_tr_b16 instead of scattering 2-byte LDS writes.
+//   NT LDS row = one m (n), BK k's:      BK*2 + 32 bytes -> 10 / 18 sixteen-byte slots (== 2 mod 4: conflict-free b128)
+//   TN LDS row = one k, BM (BN) m's:     BM*2 + 32 bytes -> 32 * odd (conflict-free transposing reads)
+// TN k map of a 32-k chunk: lane group q, element 4h+e  <->  k = 16h + 4q + e  (same for both operands).
+template <bool TN, int TM, int TNT, int BK, typename TC>
+__global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
+    constexpr int BM_ = 32 * TM, BN_ = 32 * TNT;
+    constexpr int RA = TN ? BM_ * 2 + 32 : BK * 2 + 32, RB = TN ? BN_ * 2 + 32 : BK * 2 + 32;
+    constexpr int ROWS_A = TN ? BK : BM_, ROWS_B = TN ? BK : BN_;
+    constexpr int SZA = ROWS_A * RA, SZB = ROWS_B * RB;
+    constexpr int VPA = (RA - 32) / 16, VPB = (RB - 32) / 16;          // 16-byte vectors per LDS row
+    constexpr int NVA = ROWS_A * VPA / 256, NVB = ROWS_B * VPB / 256;  // vectors per thread per stage
+    static_assert(ROWS_A * VPA % 256 == 0 && ROWS_B * VPB % 256 == 0, "staging must divide over 256 threads");
+    extern __shared__ __attribute__((aligned(16))) unsigned char dl[];
+    const bf16* A = static_cast<const bf16*>(g.A);
+    const bf16* B = static_cast<const bf16*>(g.B);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM_, n0 = blockIdx.x * BN_;
+    const int r = lane & 15, q = lane >> 4;
+
+    f32x4 acc[TM][TNT];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = acc[i][j][e];
-                const int ne = n + e;
-                if (ne < g.N) {
-                    if (g.bias) x += g.bias[ne];
-                    if (g.rowadd) x += g.rowadd[(long)(m / g.rowadd_group) * g.N + ne];
-                    if (g.act == 1) x = fmaxf(x, 0.f);
-                    if (g.accumulate) x += to_f32(C[(long)m * g.ldc + ne]);
-                }
-                v[e] = x;
-            }
-            if (vec_ok && n + 3 < g.N) {
-                store_vec4<TC>(C + (long)m * g.ldc + n, v);
-                if (g.C2) store_vec4<bf16>(g.C2 + (long)m * g.ldc2 + n, v);
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int kbeg = g.ws ? blockIdx.z * g.kper : 0;
+    const int kend = g.ws ? (kbeg + g.kper < g.K ? kbeg + g.kper : g.K) : g.K;
+
+    uint4 ra[NVA], rb[NVB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NVA; ++j) {
+            const int i = tid + j * 256, row = i / VPA, sl = i % VPA;
+            ra[j] = TN ? load_row_chunk<bf16>(A, k0 + row, g.lda, m0 + sl * 8, g.M, k0 + row < kend)
+                       : load_row_chunk<bf16>(A, m0 + row, g.lda, k0 + sl * 8, kend, m0 + row < g.M);
+        }
+#pragma unroll
+        for (int j = 0; j < NVB; ++j) {
+            const int i = tid + j * 256, row = i / VPB, sl = i % VPB;
+            rb[j] = TN ? load_row_chunk<bf16>(B, k0 + row, g.ldb, n0 + sl * 8, g.N, k0 + row < kend)
+                       : load_row_chunk<bf16>(B, n0 + row, g.ldb, k0 + sl * 8, kend, n0 + row < g.N);
+        }
+    };
+    auto stash = [&](int buf) {
+        unsigned char* As = dl + buf * (SZA + SZB);
+        unsigned char* Bs = As + SZA;
+#pragma unroll
+        for (int j = 0; j < NVA; ++j) {
+            const int i = tid + j * 256;
+            *reinterpret_cast<uint4*>(As + (i / VPA) * RA + (i % VPA) * 16) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NVB; ++j) {
+            const int i = tid + j * 256;
+            *reinterpret_cast<uint4*>(Bs + (i / VPB) * RB + (i % VPB) * 16) = rb[j];
+        }
+    };
+
+    fetch(kbeg);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK, buf ^= 1) {
+        const bool more = k0 + BK < kend;
+        if (more) fetch(k0 + BK);
+        const unsigned char* As = dl + buf * (SZA + SZB);
+        const unsigned char* Bs = As + SZA;
+#pragma unroll
+        for (int c = 0; c < BK / 32; ++c) {
+            uint4 fa[TM], fb[TNT];
+            if constexpr (!TN) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = *reinterpret_cast<const uint4*>(As + ((wm * TM + i) * 16 + r) * RA + (4 * c + q) * 16);
+#pragma unroll
+                for (int j = 0; j < TNT; ++j)
+                    fb[j] = *reinterpret_cast<const uint4*>(Bs + ((wn * TNT + j) * 16 + r) * RB + (4 * c + q) * 16);
             } else {
+                const int rq = r >> 2, p = r & 3;
+                const int kk = c * 32 + q * 4 + rq;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < g.N) {
-                        C[(long)m * g.ldc + n + e] = from_f32<TC>(v[e]);
-                        if (g.C2) g.C2[(long)m * g.ldc2 + n + e] = (bf16)v[e];
-                    }
+                for (int i = 0; i < TM; ++i) {
+                    const unsigned char* ad = As + kk * RA + ((wm * TM + i) * 16 + 4 * p) * 2;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ad));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(ad + 16 * RA));
+                    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    fa[i] = __builtin_bit_cast(uint4, f);
+                }
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) {
+                    const unsigned char* ad = Bs + kk * RB + ((wn * TNT + j) * 16 + 4 * p) * 2;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ad));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(ad + 16 * RB));
+                    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    fb[j] = __builtin_bit_cast(uint4, f);
+                }
             }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) Mma<bf16>::mma(acc[i][j], fb[j], fa[i]);  // D rows = n, D cols = m
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (g.ws) {
+        float* W = g.ws + (long)blockIdx.z * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wm * TM + i) * 16 + r;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) {
+                const int n = n0 + (wn * TNT + j) * 16 + q * 4;
+                if (n + 3 < g.N && (g.N & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(W + (long)m * g.N + n) = acc[i][j];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < g.N) W[(long)m * g.N + n + e] = acc[i][j][e];
+                }
+            }
+        }
+        return;
+    }
+    TC* C = static_cast<TC*>(g.C);
+    const bool vec_ok = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                        (g.C2 == nullptr || g.ldc2 % 4 == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm * TM + i) * 16 + r;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) {
+            const int n = n0 + (wn * TNT + j) * 16 + q * 4;
+            if (n >= g.N) continue;
+            epilogue_store<TC>(g, C, m, n, acc[i][j], vec_ok);
         }
     }
 }
@@ -175,11 +333,38 @@ __global__ void gemm_splitk_reduce(GemmArgs g, int splits) {
     }
 }
 
+template <bool TN, int TM, int TNT, int BK, typename TC>
+void launch_bf16(hipStream_t s, const GemmArgs& g, int splits) {
+    constexpr int BM_ = 32 * TM, BN_ = 32 * TNT;
+    constexpr int lds = 2 * ((TN ? BK : BM_) * (TN ? BM_ * 2 + 32 : BK * 2 + 32) +
+                             (TN ? BK : BN_) * (TN ? BN_ * 2 + 32 : BK * 2 + 32));
+    auto k = gemm_bf16<TN, TM, TNT, BK, TC>;
+    static bool attr_set = false;   // benign race: the attribute is idempotent
+    if (lds > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    dim3 grid((g.N + BN_ - 1) / BN_, (g.M + BM_ - 1) / BM_, splits);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, g);
+}
+
 template <typename T, typename TC>
 int launch(hipStream_t s, int trans, const GemmArgs& g, int splits) {
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
-    if (trans) hipLaunchKernelGGL((gemm_kernel<T, TC, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<T, TC, false>), grid, dim3(256), 0, s, g);
+    if constexpr (sizeof(T) == 2) {
+        // 128x128 tiles once they alone fill most of the chip, 64x64 (with the caller's split-K) otherwise
+        const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+        if (splits == 1 && big >= 160) {
+            if (trans) launch_bf16<true, 4, 4, 64, TC>(s, g, splits);
+            else launch_bf16<false, 4, 4, 64, TC>(s, g, splits);
+        } else {
+            if (trans) launch_bf16<true, 2, 2, 128, TC>(s, g, splits);
+            else launch_bf16<false, 2, 2, 128, TC>(s, g, splits);
+        }
+    } else {
+        dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
+        if (trans) hipLaunchKernelGGL((gemm_kernel<T, TC, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_kernel<T, TC, false>), grid, dim3(256), 0, s, g);
+    }
     if (g.ws) {
         long blocks = ((long)g.M * g.N + 255) / 256;
         hipLaunchKernelGGL(gemm_splitk_reduce<TC>, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, g,
@@ -198,7 +383,7 @@ extern "C" int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K,
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return VQA_ERR_ARG;
     if (rowadd && rowadd_group <= 0) return VQA_ERR_ARG;
     if (splits < 1 || (splits > 1 && !splitk_ws)) return VQA_ERR_ARG;
-    const int kc = dtype == VQA_BF16 ? 32 : 16;
+    const int kc = dtype == VQA_BF16 ? 128 : 16;   // split boundaries on whole pipeline stages
     const int kper = ((K + splits - 1) / splits + kc - 1) / kc * kc;
     splits = splits > 1 ? (K + kper - 1) / kper : 1;
     GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, bias, rowadd, rowadd_group, act, accumulate,

@@ -12,7 +12,7 @@ def pad8(n):
 
 
 def gemm(A, B, trans=False, M=None, N=None, K=None, out=None, out_dtype=torch.float32, bias=None, rowadd=None,
-         group=1, act=0, accumulate=False, c2=None):
+         group=1, act=0, accumulate=False, c2=None, splits=None):
     """NT: out[M,N] = A[M,K] @ B[N,K]^T.   TN (trans=True): out[M,N] = A[K,M]^T @ B[K,N].
     A / B may be row-strided views (stride(1) == 1).  Epilogue: + bias[n] + rowadd[m // group, n], ReLU (act=1),
     accumulate into `out`, optional bf16 copy `c2`."""
@@ -28,11 +28,14 @@ def gemm(A, B, trans=False, M=None, N=None, K=None, out=None, out_dtype=torch.fl
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=out_dtype)
     assert out.stride(1) == 1
-    # split-K when the output grid alone cannot fill 256 CUs and the reduction is long
+    # split-K when the 64x64 output grid alone cannot fill 256 CUs (2 workgroups each) and the reduction is long;
+    # thresholds from scripts/gemm_micro.py + rocprofv3 on the step's shapes
     blocks = -(-M // 64) * -(-N // 64)
-    splits = 1
-    if blocks < 384 and K >= 512:
-        splits = max(1, min(16, 768 // blocks, K // 256))
+    if splits is None:
+        if blocks >= 160:
+            splits = 2 if (K >= 3072 and blocks < 384) else 1
+        else:
+            splits = max(1, min(K // 384, 320 // blocks, 16))
     ws = torch.empty(splits, M, N, device=A.device, dtype=torch.float32) if splits > 1 else None
     tag = dict(kind='tn' if trans else 'nt', shape=f'{M}x{N}x{K}', flops=2.0 * M * N * K,
                bytes=float((M * K + N * K) * A.element_size() + M * N * out.element_size()))

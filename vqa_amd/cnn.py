@@ -22,7 +22,7 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 CIN0_PAD = 16          # the 3 image channels are zero-padded to one MFMA k-group
 
 
-def pick_tile(oh, ow, mt_max=256, patch_max=640):
+def pick_tile(oh, ow, mt_max=256, patch_max=384):
     """(R, CW): output-tile rows x cols of one workgroup.  Fewest tiles first, then the smallest halo."""
     best = None
     for cw in range(1, min(ow, mt_max) + 1):

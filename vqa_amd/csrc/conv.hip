@@ -83,27 +83,62 @@ __global__ __launch_bounds__(256) void conv3x3_igemm(ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < NBF; ++n) acc[f][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- staging plan.  Every thread moves up to NPV patch vectors and NWV weight vectors per channel chunk.  The
+    // loads are branch-free (out-of-image / out-of-range lanes read a valid dummy address and are zeroed by a
+    // select) so that all of a chunk's loads are in flight together, and the loads of chunk ch+1 are issued before
+    // the MFMA phase of chunk ch and written to LDS after it (register prefetch, single LDS buffer).
+    constexpr int PMAX = 384;                                   // host bound on (R+2)*(CW+2)
+    constexpr int NPV = (PMAX * VPP + 255) / 256;
+    constexpr int WV = KP / VEC;                                // vectors per weight row
+    constexpr int NWV = (NB * WV + 255) / 256;
+    const T* xb = x + (long)b * a.IH * a.IW * a.Cin;
+    int psrc[NPV];                                              // element offset inside the image
+    unsigned pmask[NPV];                                        // all-ones, or 0 = zero fill (AND, not a select: a
+                                                                // select lets hipcc branch around the load again)
+#pragma unroll
+    for (int j = 0; j < NPV; ++j) {
+        const int i = tid + j * 256;
+        const int px = i / VPP, vv = i % VPP;
+        const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
+        const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
+        const bool ok = i < PPIX * VPP && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+        psrc[j] = ok ? (iy * a.IW + ix) * a.Cin + vv * VEC : 0;
+        pmask[j] = ok ? 0xFFFFFFFFu : 0u;
+    }
+    uint4 pv[NPV], wv[NWV];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < NPV; ++j) {
+            pv[j] = *reinterpret_cast<const uint4*>(xb + psrc[j] + ch * CK);   // masked in stash(): no wait here
+        }
+        const T* wsrc = w + ((long)ch * a.Cout + co0) * KP;     // the chunk's NB rows are contiguous
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
+            const int i = tid + j * 256;
+            wv[j] = *reinterpret_cast<const uint4*>(wsrc + (i < NB * WV ? i : 0) * VEC);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPV; ++j) {
+            const int i = tid + j * 256;
+            const uint4 t = make_uint4(pv[j].x & pmask[j], pv[j].y & pmask[j], pv[j].z & pmask[j], pv[j].w & pmask[j]);
+            if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + (i / VPP) * PXB + (i % VPP) * 16) = t;
+        }
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
+            const int i = tid + j * 256;
+            const uint4 t = wv[j];   // by value first: a conditional store straight from the array keeps it in scratch
+            if (i < NB * WV) *reinterpret_cast<uint4*>(wl + (i / WV) * WROWB + (i % WV) * 16) = t;
+        }
+    };
+
     const int nchunks = a.Cin / CK;
+    fetch(0);
     for (int ch = 0; ch < nchunks; ++ch) {
-        // ---- stage the input patch (zero outside the image) and the weight slab
-        for (int i = tid; i < PPIX * VPP; i += 256) {
-            const int px = i / VPP, vv = i % VPP;
-            const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
-            const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
-                v = *reinterpret_cast<const uint4*>(x + ((long)(b * a.IH + iy) * a.IW + ix) * a.Cin + ch * CK +
-                                                    vv * VEC);
-            *reinterpret_cast<uint4*>(patch + px * PXB + vv * 16) = v;
-        }
-        constexpr int WV = KP / VEC;  // vectors per weight row
-        const T* wsrc = w + ((long)ch * a.Cout + co0) * KP;
-        for (int i = tid; i < NB * WV; i += 256) {
-            const int row = i / WV, kv = i % WV;
-            *reinterpret_cast<uint4*>(wl + row * WROWB + kv * 16) =
-                *reinterpret_cast<const uint4*>(wsrc + (long)row * KP + kv * VEC);
-        }
+        stash();
         __syncthreads();
+        if (ch + 1 < nchunks) fetch(ch + 1);
         // ---- MFMA over 9 taps x CK channels
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -476,7 +511,7 @@ extern "C" int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const voi
                                const float* bias, float* stats, int B, int IH, int IW, int Cin, int OH, int OW,
                                int Cout, int pad, int R, int CW) {
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || R * CW > 256 ||
-        (R + 2) * (CW + 2) > 640)
+        (R + 2) * (CW + 2) > 384)
         return VQA_ERR_ARG;
     ConvArgs a{x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, (OW + CW - 1) / CW,
                (OH + R - 1) / R, 1.0f / CW, 1.0f / (CW + 2), 1.0f / ((OW + CW - 1) / CW)};

@@ -96,8 +96,13 @@ def conv_wgrad(x, dy, cin_real, pad):
     pairs = (-(-cout // 64)) * (cin // ck)
     esz = x.element_size()
     pxb = 32 if ck * esz == 32 else ck * esz + 32
-    lds = (R + 2) * (CW + 2) * pxb + (-(-R * CW // (64 // esz)) * (64 // esz)) * (64 * esz + 32)
-    per_cu = max(1, min(3 if ck == 16 else 2, (160 * 1024) // lds))
+    cow = min(cout, 64)                                   # output channels per workgroup (conv.hip dy_stride)
+    dyb = (32 if cow == 16 else cow * 2 + 32) if esz == 2 else (64 if cow == 16 else cow * 4 + 64)
+    kc = 64 // esz
+    lds = (R + 2) * (CW + 2) * pxb + (-(-R * CW // kc) * kc) * dyb
+    # resident workgroups per CU: register-limited waves/SIMD of the instantiation, then LDS
+    waves = 2 if ck == 32 else (4 if cow == 16 else 3)
+    per_cu = max(1, min(waves, (160 * 1024) // lds))
     G = max(1, min(tiles, (256 * per_cu) // pairs if pairs <= 256 * per_cu else 1))
     part = torch.empty(G, cout, 9, cin, device=x.device, dtype=torch.float32)
     dw = torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)

@@ -240,7 +240,6 @@ struct WgradArgs {
     float* part;     // [G][Cout][9][Cin] partial sums
     int B, IH, IW, Cin, OH, OW, Cout, pad;
     int R, CW, tiles_x, tiles_y;
-    int nwk;  // waves along the pixel (reduction) axis: 4 / min(4, Cout/16)
     float inv_cw, inv_pw, inv_tx, inv_tiles;
 };
 
@@ -248,11 +247,18 @@ struct WgradArgs {
 // t = blockIdx.x, blockIdx.x + gridDim.x, ...  The 4 waves split as (4/nwk output-channel fragments) x (nwk slices
 // of the pixel reduction), so layers with 16 or 32 output channels still use every wave; the slices are combined
 // through LDS at the end and each workgroup writes one partial slab.
-template <typename T, int CK>
+// LDS bytes per dy-tile pixel (COW channels): 32 * odd for the bf16 transposing reads; for f32 (lane group q reads
+// pixel q, 16 lanes x 4 bytes each) 64 or 192 (mod 256) puts the 4 pixels of one read on disjoint banks.
+__host__ __device__ constexpr int dy_stride(int esz, int cow) {
+    return esz == 2 ? (cow == 16 ? 32 : cow * 2 + 32) : (cow == 16 ? 64 : cow * 4 + 64);
+}
+
+template <typename T, int CK, int COW>
 __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     constexpr int VEC = Mma<T>::VEC, KC = 4 * VEC;
     constexpr int PXB = pix_stride(CK * (int)sizeof(T));
-    constexpr int NB = 64, DYB = NB * (int)sizeof(T) + 32;
+    constexpr int DYB = dy_stride((int)sizeof(T), COW);
+    constexpr int nwco = COW / 16, nwk = 4 / nwco;   // waves: (output-channel fragments) x (pixel-reduction slices)
     constexpr int VPP = CK * (int)sizeof(T) / 16;
     constexpr int CF = CK / 16;  // input-channel fragments
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -263,10 +269,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int nco = (a.Cout + NB - 1) / NB;
-    const int co0 = (blockIdx.y % nco) * NB, ci0 = (blockIdx.y / nco) * CK;
-    const int cow = a.Cout - co0 < NB ? a.Cout - co0 : NB;  // valid output channels of this block
-    const int nwco = 4 / a.nwk;
+    const int nco = a.Cout / COW;
+    const int co0 = (blockIdx.y % nco) * COW, ci0 = (blockIdx.y / nco) * CK;
     const int wco = wave % nwco, wk = wave / nwco;
     const T* x = static_cast<const T*>(a.x);
     const T* dy = static_cast<const T*>(a.dy);
@@ -281,10 +285,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     // Software pipeline over pixel tiles: the global loads of tile t+1 are issued into registers before the MFMA
     // loop of tile t and written to LDS after it, so HBM latency hides under compute even at 1-2 blocks per CU.
     constexpr int PMAX = sizeof(T) == 2 ? 512 : 320;               // host bound on (R+2)*(CW+2)
-    constexpr int NPV = (PMAX * VPP + 255) / 256, NDV = 8;         // 16-byte vectors per thread: patch, dy tile
+    constexpr int dvp = COW / VEC;                                 // 16-byte vectors per dy pixel
+    constexpr int dsh = dvp == 16 ? 4 : (dvp == 8 ? 3 : (dvp == 4 ? 2 : 1));
+    constexpr int NPV = (PMAX * VPP + 255) / 256;                  // 16-byte vectors per thread: patch,
+    constexpr int NDV = (sizeof(T) == 2 ? 256 : 128) * dvp / 256;  // dy tile (MT <= 256 / 128 pixels)
     uint4 pv[NPV], dv[NDV];
-    const int dvp = cow / VEC;   // 16-byte vectors per pixel that hold real channels (cow = 16, 32 or 64)
-    const int dsh = dvp == 16 ? 4 : (dvp == 8 ? 3 : (dvp == 4 ? 2 : (dvp == 2 ? 1 : 0)));
     auto fetch = [&](int t) {
         const int b = fastdiv(t, tiles, a.inv_tiles), tl = t - b * tiles;
         const int tyy = fastdiv(tl, a.tiles_x, a.inv_tx);
@@ -333,8 +338,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
         stash();
         __syncthreads();
         if (t + (int)gridDim.x < total) fetch(t + gridDim.x);
-        if (wco * 16 < cow) {
-            for (int ks = wk * KC; ks < MTP; ks += a.nwk * KC) {
+        {
+            for (int ks = wk * KC; ks < MTP; ks += nwk * KC) {
                 if constexpr (sizeof(T) == 2) {
                     // bf16: lane i = 4*rq + p of a 16-lane group supplies the address of k-row rq, channels 4p..4p+3;
                     // it receives channel i of 4 k-rows.  Two reads = the 8 k (pixels) of lane group q.
@@ -401,9 +406,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
         __syncthreads();
     }
     // combine the pixel slices of the block in LDS (fixed order), then one partial slab per workgroup
-    if (a.nwk > 1) {
+    if constexpr (nwk > 1) {
         float* red = reinterpret_cast<float*>(smem);   // staging LDS is free after the loop's last barrier
-        if (wk > 0 && wco * 16 < cow) {
+        if (wk > 0) {
             float* dst = red + ((long)((wk - 1) * nwco + wco) * 9 * CF) * 256 + lane * 4;
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp)
@@ -412,8 +417,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
                     *reinterpret_cast<f32x4*>(dst + (tp * CF + c) * 256) = acc[tp][c];
         }
         __syncthreads();
-        if (wk == 0 && wco * 16 < cow) {
-            for (int k = 1; k < a.nwk; ++k) {
+        if (wk == 0) {
+            for (int k = 1; k < nwk; ++k) {
                 const float* src = red + ((long)((k - 1) * nwco + wco) * 9 * CF) * 256 + lane * 4;
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp)
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
         }
     }
     // D rows = co (4q+e), D cols = ci (r)
-    if (wk == 0 && wco * 16 < cow) {
+    if (wk == 0) {
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
@@ -535,8 +540,10 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
                                  int pad, int R, int CW) {
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || G < 1) return VQA_ERR_ARG;
     const int tx_ = (OW + CW - 1) / CW, ty_ = (OH + R - 1) / R;
-    const int nwk = Cout >= 64 ? 1 : (Cout >= 32 ? 2 : 4);
-    WgradArgs a{x, dy, part, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_, nwk,
+    const int COW = Cout >= 64 ? 64 : Cout;      // output channels per workgroup
+    if ((COW != 16 && COW != 32 && COW != 64) || Cout % COW) return VQA_ERR_ARG;
+    const int nwk = 64 / COW;
+    WgradArgs a{x, dy, part, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
                 1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_)};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int MT = R * CW, PPIX = (R + 2) * (CW + 2);
@@ -544,22 +551,26 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     auto go = [&](auto kern, int CK, int esz) {
         const int KC = 64 / esz;
         const int MTP = (MT + KC - 1) / KC * KC;
-        size_t lds = (size_t)(PPIX * pix_stride(CK * esz) + 15) / 16 * 16 + (size_t)MTP * (64 * esz + 32);
+        size_t lds = (size_t)(PPIX * pix_stride(CK * esz) + 15) / 16 * 16 + (size_t)MTP * dy_stride(esz, COW);
         const size_t red = (size_t)(nwk - 1) * (4 / nwk) * 9 * (CK / 16) * 1024;   // cross-slice combine buffer
         if (lds < red) lds = red;
         if (lds > 160 * 1024) return VQA_ERR_ARG;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        dim3 grid(G, ((Cout + 63) / 64) * (Cin / CK));
+        dim3 grid(G, (Cout / COW) * (Cin / CK));
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
         return hipGetLastError() == hipSuccess ? VQA_OK : VQA_ERR_LAUNCH;
     };
     if (dtype == VQA_BF16) {
         if (MT > 256 || PPIX > 512) return VQA_ERR_ARG;
-        if (Cin % 32 == 0) status = go(conv3x3_wgrad<bf16, 32>, 32, 2);
-        else if (Cin == 16) status = go(conv3x3_wgrad<bf16, 16>, 16, 2);
+#define GO_COW(T, CK, ESZ)                                                       \
+    (COW == 64 ? go(conv3x3_wgrad<T, CK, 64>, CK, ESZ)                           \
+               : (COW == 32 ? go(conv3x3_wgrad<T, CK, 32>, CK, ESZ) : go(conv3x3_wgrad<T, CK, 16>, CK, ESZ)))
+        if (Cin % 32 == 0) status = GO_COW(bf16, 32, 2);
+        else if (Cin == 16) status = GO_COW(bf16, 16, 2);
     } else if (dtype == VQA_F32) {
         if (MT > 128 || PPIX > 320) return VQA_ERR_ARG;
-        if (Cin % 16 == 0) status = go(conv3x3_wgrad<float, 16>, 16, 4);
+        if (Cin % 16 == 0) status = GO_COW(float, 16, 4);
+#undef GO_COW
     }
     if (status != VQA_OK) return status;
     const int n = Cout * 9 * Cin;

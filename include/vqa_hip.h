@@ -31,12 +31,23 @@ int vqa_conv_pack(void* stream, int dtype, const float* w, void* out, int Cout, 
                   int dgrad);
 
 /* nn.Conv2d(k=3, stride 1, padding=pad) forward (cnn.py:23-40) as implicit GEMM on MFMA; also the data gradient
- * when called on dy with a dgrad slab and pad' = 2 - pad.  y = conv(x) + bias.  `stats` (may be NULL) receives one
- * row of per-channel (sum, sum of squares) of y per workgroup for the BatchNorm that follows:
- * vqa_conv3x3_stat_rows() rows of [Cout][2].  R x CW (<= 256 pixels) is the output tile of one workgroup. */
+ * when called on dy with a dgrad slab and pad' = 2 - pad.  y = conv(x) + bias.  R x CW (<= 256 pixels) is the output
+ * tile; G persistent workgroups per output-channel block walk the (image, tile) pairs - take G from
+ * vqa_conv3x3_plan() (resident workgroups of the instantiation x 256 CUs; -1 = unsupported shape).  `stats` (may be
+ * NULL) receives G rows of per-channel (sum, sum of squares) of y, [G][Cout][2], for the BatchNorm that follows. */
 int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked, void* y, const float* bias,
-                    float* stats, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW);
-int vqa_conv3x3_stat_rows(int B, int OH, int OW, int R, int CW);
+                    float* stats, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW,
+                    int G);
+int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW);
+
+/* First encoder layer, bf16 path: nn.Conv2d(3, 16, 3, padding=pad) (cnn.py:23) straight from the NCHW image
+ * (in_dtype f16 / f32 / bf16; dataset.py:96-98 stores f16) - no NHWC copy, no channel padding: k = (c, ky, kx) = 27
+ * is one 32-deep MFMA.  w is the f32 master weight [16][3][3][3]; y is NHWC bf16 [B][OH][OW][16]; stats as in
+ * vqa_conv3x3_fwd.  _wgrad: dw [16][3][3][3] f32 from dy (NHWC bf16) and the image; part = [G][16][32] f32. */
+int vqa_conv3x3_first_fwd(void* stream, int in_dtype, const void* images, const float* w, void* y, const float* bias,
+                          float* stats, int B, int IH, int IW, int OH, int OW, int pad, int R, int CW);
+int vqa_conv3x3_first_wgrad(void* stream, int in_dtype, const void* images, const void* dy, float* part, float* dw,
+                            int G, int B, int IH, int IW, int OH, int OW, int pad, int R, int CW);
 
 /* Conv2d weight gradient (autograd of cnn.py:23-40): dw [Cout][Cin_real][3][3] f32 = sum over pixels of dy (x) x.
  * `part` is a [G][Cout][9][Cin] f32 workspace (one partial slab per workgroup group, summed in fixed order). */

@@ -52,6 +52,36 @@ def test_conv_fwd_dgrad_wgrad_exact(prec, B, cin, cout, H, W, pad):
     assert torch.equal(dw.cpu(), wr.grad)
 
 
+@pytest.mark.parametrize('img_dtype', [torch.float16, torch.float32])
+@pytest.mark.parametrize('B,H,W,pad', [(2, 20, 20, 2), (3, 13, 37, 0), (1, 70, 226, 2), (2, 33, 18, 5), (2, 9, 9, 1)])
+def test_first_layer_exact(img_dtype, B, H, W, pad):
+    """Dedicated Conv2d(3, 16) kernels on the NCHW image: small-integer data, bit-exact forward, statistics and
+    weight gradient (the generic kernels on the channel-padded NHWC copy are the second witness)."""
+    from vqa_amd import cnn as C
+    torch.manual_seed(B * 100 + H + W + pad)
+    x = _ints((B, 3, H, W), -2, 3)
+    w = _ints((16, 3, 3, 3), -2, 3)
+    bias = _ints((16,), -3, 4)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(x, wr, bias, padding=pad)
+    dy = _ints(tuple(y_ref.shape), -2, 3)
+    y_ref.backward(dy)
+    img = x.to(img_dtype).cuda()
+    assert C.first_ok(img, w, torch.bfloat16)
+    y, stats = C.first_fwd(img, w.cuda(), bias.cuda(), pad, True)
+    y_st = y_ref.detach().bfloat16().float()
+    assert torch.equal(y.float().cpu().permute(0, 3, 1, 2), y_st)
+    s = stats.sum(0).cpu()
+    assert torch.allclose(s[:, 0], y_st.sum((0, 2, 3)), rtol=1e-5)
+    assert torch.allclose(s[:, 1], (y_st ** 2).sum((0, 2, 3)), rtol=1e-5)
+    dw = C.first_wgrad(img, _nhwc(dy, torch.bfloat16), pad)
+    assert torch.equal(dw.cpu(), wr.grad)
+    # second witness: the generic path on the padded NHWC copy
+    xd = C.to_nhwc(img, torch.bfloat16)
+    y2, _ = C.conv_fwd(xd, C.pack_weights(w.cuda(), C.CIN0_PAD, torch.bfloat16, dgrad=False), bias.cuda(), 16, pad, True)
+    assert torch.equal(y2, y)
+
+
 @pytest.mark.parametrize('prec,tol', [('fp32', 1e-5), ('bf16', 2e-2)])
 @pytest.mark.parametrize('pool', [0, 1, 2])
 @pytest.mark.parametrize('C', [16, 64, 256])

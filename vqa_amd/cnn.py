@@ -75,15 +75,26 @@ def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd'):
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
     R, CW = pick_tile(OH, OW)
     y = torch.empty(B, OH, OW, cout, device=x.device, dtype=x.dtype)
-    stats = None
-    if want_stats:
-        rows = B * (-(-OH // R)) * (-(-OW // CW))
-        stats = torch.empty(rows, cout, 2, device=x.device, dtype=torch.float32)
+    G = _plan(L.dt(x), B, IH, IW, cin, OH, OW, cout, pad, R, CW)
+    stats = torch.empty(G, cout, 2, device=x.device, dtype=torch.float32) if want_stats else None
     cr = cin if cin_real is None else cin_real
     tag = _conv_tag(kind, B, OH, OW, cr, cout, x,
                     y.numel() * y.element_size(), wpk.numel() * wpk.element_size())
-    L.call('vqa_conv3x3_fwd', L.dt(x), x, wpk, y, bias, stats, B, IH, IW, cin, OH, OW, cout, pad, R, CW, tag=tag)
+    L.call('vqa_conv3x3_fwd', L.dt(x), x, wpk, y, bias, stats, B, IH, IW, cin, OH, OW, cout, pad, R, CW, G, tag=tag)
     return y, stats
+
+
+_plans = {}
+
+
+def _plan(*key):
+    """Persistent-grid size of a conv shape (an occupancy query in the library, cached per shape)."""
+    if key not in _plans:
+        g = L.lib().vqa_conv3x3_plan(*[L.ctypes.c_int(int(v)) for v in key])
+        if g < 1:
+            raise L.VqaHipError(f'vqa_conv3x3_plan: unsupported conv shape {key}')
+        _plans[key] = g
+    return _plans[key]
 
 
 def conv_wgrad(x, dy, cin_real, pad):
@@ -127,12 +138,49 @@ def to_nhwc(images, dtype):
     return out
 
 
-def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training):
-    """conv3x3 -> BatchNorm -> ReLU -> (pool).  x NHWC.  Returns (a, saved) with saved = (x, y, scale, shift,
-    mean, invstd) for block_bwd."""
-    dev, dtype, cout = x.device, x.dtype, w.shape[0]
-    wpk = pack_weights(w, x.shape[3], dtype, dgrad=False)
-    y, stats = conv_fwd(x, wpk, bias, cout, pad, training, cin_real=w.shape[1])
+def first_ok(images, w, dtype):
+    """The dedicated first-layer kernels take the NCHW image as it is (bf16 path, Conv2d(3, 16))."""
+    return (dtype == torch.bfloat16 and tuple(w.shape) == (16, 3, 3, 3) and images.dim() == 4 and
+            images.shape[1] == 3 and images.dtype in (torch.float16, torch.float32, torch.bfloat16))
+
+
+def first_fwd(images, w, bias, pad, want_stats):
+    B, _, IH, IW = images.shape
+    OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
+    R, CW = pick_tile(OH, OW)
+    y = torch.empty(B, OH, OW, 16, device=images.device, dtype=torch.bfloat16)
+    stats = None
+    if want_stats:
+        stats = torch.empty(B * (-(-OH // R)) * (-(-OW // CW)), 16, 2, device=images.device, dtype=torch.float32)
+    tag = dict(kind='first', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
+               bytes=float(images.numel() * images.element_size() + y.numel() * 2 + w.numel() * 4))
+    L.call('vqa_conv3x3_first_fwd', L.dt(images), images, w, y, bias, stats, B, IH, IW, OH, OW, pad, R, CW, tag=tag)
+    return y, stats
+
+
+def first_wgrad(images, dy, pad):
+    B, _, IH, IW = images.shape
+    _, OH, OW, _ = dy.shape
+    R, CW = pick_tile(OH, OW)
+    tiles = B * (-(-OH // R)) * (-(-OW // CW))
+    G = min(tiles, 256 * 6)
+    part = torch.empty(G, 16, 32, device=dy.device, dtype=torch.float32)
+    dw = torch.empty(16, 3, 3, 3, device=dy.device, dtype=torch.float32)
+    tag = dict(kind='first_wgrad', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
+               bytes=float(images.numel() * images.element_size() + dy.numel() * 2))
+    L.call('vqa_conv3x3_first_wgrad', L.dt(images), images, dy, part, dw, G, B, IH, IW, OH, OW, pad, R, CW, tag=tag)
+    return dw
+
+
+def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False):
+    """conv3x3 -> BatchNorm -> ReLU -> (pool).  x NHWC (first=True: the NCHW image, dedicated kernel).  Returns
+    (a, saved) with saved = (x, y, scale, shift, mean, invstd) for block_bwd."""
+    dev, cout = x.device, w.shape[0]
+    if first:
+        y, stats = first_fwd(x, w, bias, pad, training)
+    else:
+        wpk = pack_weights(w, x.shape[3], x.dtype, dgrad=False)
+        y, stats = conv_fwd(x, wpk, bias, cout, pad, training, cin_real=w.shape[1])
     scale = torch.empty(cout, device=dev, dtype=torch.float32)
     shift, mean, invstd = torch.empty_like(scale), torch.empty_like(scale), torch.empty_like(scale)
     if training:
@@ -149,7 +197,7 @@ def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training):
     return a, (x, y, scale, shift, mean, invstd)
 
 
-def block_bwd(d, saved, w, cin_real, pad, pool, need_dx):
+def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False):
     """d = gradient w.r.t. the block output (NHWC, activation dtype).  Returns (dx, dw, dbias, dgamma, dbeta)."""
     x, y, scale, shift, mean, invstd = saved
     dev = y.device
@@ -168,7 +216,7 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx):
                                         L.ptr(dbeta), L.ptr(c1), L.ptr(c2)), 'vqa_bn_bwd_finalize')
     tag = dict(kind='apply', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((2 * y.numel() + d.numel()) * es))
     L.call('vqa_bn_bwd', L.dt(y), 1, y, d, dy, scale, shift, mean, invstd, c1, c2, None, B, H, W, C, pool, tag=tag)
-    dw = conv_wgrad(x, dy, cin_real, pad)
+    dw = first_wgrad(x, dy, pad) if first else conv_wgrad(x, dy, cin_real, pad)
     # the conv bias feeds a training-mode BatchNorm: its gradient is identically zero (the reference produces
     # rounding noise ~1e-7 of the weight-gradient scale here)
     dbias = torch.zeros(C, device=dev, dtype=torch.float32)
@@ -186,17 +234,19 @@ class _CnnFunction(torch.autograd.Function):
     def forward(ctx, images, cfg, *tensors):
         padding, pool_mode, training, dtype = cfg
         params, buffers = tensors[:40], tensors[40:]
-        x = to_nhwc(images, dtype)
+        first = first_ok(images, params[0], dtype)
+        x = images.contiguous() if first else to_nhwc(images, dtype)
         saved, meta = [], []
         for li in range(10):
             w, bias, gamma, beta = params[4 * li: 4 * li + 4]
             pad = padding if li in (0, 2, 4, 6) else 0
             pool = pool_mode if li % 2 == 1 else 0
-            x, sv = block_fwd(x, w, bias, gamma, beta, buffers[2 * li], buffers[2 * li + 1], pad, pool, training)
+            x, sv = block_fwd(x, w, bias, gamma, beta, buffers[2 * li], buffers[2 * li + 1], pad, pool, training,
+                              first=first and li == 0)
             saved += list(sv)
             meta.append((pad, pool))
         ctx.save_for_backward(*saved, *params)
-        ctx.meta, ctx.cfg = meta, cfg
+        ctx.meta, ctx.cfg, ctx.first = meta, cfg, first
         B, PH, PW, C = x.shape
         return x.reshape(B, PH * PW, C).float()
 
@@ -213,7 +263,7 @@ class _CnnFunction(torch.autograd.Function):
         for li in range(9, -1, -1):
             pad, pool = ctx.meta[li]
             d, dw, db, dg, dbt = block_bwd(d, saved[6 * li: 6 * li + 6], params[4 * li], CHANNELS[li], pad, pool,
-                                           li > 0)
+                                           li > 0, first=ctx.first and li == 0)
             grads[4 * li: 4 * li + 4] = [dw, db, dg, dbt]
         return (None, None, *grads, *([None] * 20))
 

@@ -30,7 +30,7 @@ struct ConvArgs {
     float* stats;       // [tiles*B][Cout][2] partial (sum, sumsq) or null
     int B, IH, IW, Cin, OH, OW, Cout, pad;
     int R, CW, tiles_x, tiles_y;
-    float inv_cw, inv_pw, inv_tx;
+    float inv_cw, inv_pw, inv_tx, inv_tiles;
 };
 
 template <typename T, int CK> struct ConvCfg {
@@ -44,8 +44,10 @@ template <typename T, int CK> struct ConvCfg {
 };
 
 // ---------------------------------------------------------------------------------------------- igemm
+// One workgroup per (tile, image, channel block): the multi-chunk (Cin > CK) layers, which are MFMA-bound and
+// want their registers for the accumulators and the chunk prefetch rather than for persistent-loop state.
 template <typename T, int CK, int NBF>
-__global__ __launch_bounds__(256) void conv3x3_igemm(ConvArgs a) {
+__global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     using Cfg = ConvCfg<T, CK>;
     constexpr int VEC = Cfg::VEC, KC = Cfg::KC, KP = Cfg::KP, NS = Cfg::NS, PXB = Cfg::PXB, WROWB = Cfg::WROWB,
                   VPP = Cfg::VPP;
@@ -210,27 +212,229 @@ __global__ __launch_bounds__(256) void conv3x3_igemm(ConvArgs a) {
     }
 }
 
+
+// Persistent single-chunk variant (Cin == CK: the HBM-bound early layers and their data gradients).
+// grid = (G, Cout / NB); workgroup g walks the (image, tile) pairs t = g, g + G, ...  A wave64 VALU instruction
+// occupies its SIMD for 4 cycles, and at one workgroup per tile the per-tile index arithmetic alone (~370 VALU per
+// wave for 64 output pixels) was what held these layers at ~3.5 TB/s.  Here everything that does not depend on the
+// tile is computed once per workgroup (fragment pixel decode, patch vector coordinates), the weight slab and the bias
+// stay resident in LDS, the next tile's patch is prefetched into registers during the MFMAs, and the BatchNorm
+// partial sums stay in registers across tiles: ONE statistics row per workgroup.
 template <typename T, int CK, int NBF>
-int launch_igemm(hipStream_t s, const ConvArgs& a) {
+__global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
+    using Cfg = ConvCfg<T, CK>;
+    constexpr int VEC = Cfg::VEC, KC = Cfg::KC, KP = Cfg::KP, NS = Cfg::NS, PXB = Cfg::PXB, WROWB = Cfg::WROWB,
+                  VPP = Cfg::VPP;
+    constexpr int NB = NBF * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int PW = a.CW + 2, PPIX = (a.R + 2) * PW;
+    unsigned char* patch = smem;
+    unsigned char* wl = smem + (PPIX * PXB + 15) / 16 * 16;
+    float* biasl = reinterpret_cast<float*>(wl + NB * WROWB);   // [NB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int co0 = blockIdx.y * NB;
+    const int MT = a.R * a.CW;
+    const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
+    const T* x = static_cast<const T*>(a.x);
+    const T* w = static_cast<const T*>(a.w);
+    T* y = static_cast<T*>(a.y);
+    if ((int)blockIdx.x >= total) return;                       // (host launches G <= total)
+
+    // ---- once per workgroup: fragment pixel decode (4 fragments of 16 consecutive tile pixels per wave);
+    // (row, col) packed as row << 16 | col, rows of pixels beyond the tile are "never inside the image"
+    int pbase[4], frc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int m = (wave * 4 + f) * 16 + r;
+        int pr = 0, pc = 0;
+        if (m < MT) { pr = fastdiv(m, a.CW, a.inv_cw); pc = m - pr * a.CW; }
+        pbase[f] = (pr * PW + pc) * PXB;
+        frc[f] = ((m < MT ? pr : 0x4000) << 16) | pc;
+    }
+    // ---- once per workgroup: coordinates of the patch vectors this thread stages, (py - pad) << 16 | (px - pad + 64)
+    constexpr int PMAX = 384;                                   // host bound on (R+2)*(CW+2)
+    constexpr int NPV = (PMAX * VPP + 255) / 256;
+    constexpr int WV = KP / VEC;                                // vectors per weight row
+    int prel[NPV], pyx[NPV];
+#pragma unroll
+    for (int j = 0; j < NPV; ++j) {
+        const int i = tid + j * 256;
+        const int px = i / VPP, vv = i % VPP;
+        const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
+        pyx[j] = ((i < PPIX * VPP ? py - a.pad : -0x4000) << 16) | (pxx - a.pad + 64);
+        prel[j] = ((py - a.pad) * a.IW + (pxx - a.pad)) * a.Cin + vv * VEC;
+    }
+    // ---- once per workgroup: weight slab and bias into LDS
+    {
+        const T* wsrc = w + (long)co0 * KP;
+        for (int i = tid; i < NB * WV; i += 256)
+            *reinterpret_cast<uint4*>(wl + (i / WV) * WROWB + (i % WV) * 16) =
+                *reinterpret_cast<const uint4*>(wsrc + (long)i * VEC);
+        if (tid < NB) biasl[tid] = a.bias ? a.bias[co0 + tid] : 0.f;
+    }
+
+    f32x4 acc[4][NBF];
+    float s1[NBF][4], s2[NBF][4];
+#pragma unroll
+    for (int n = 0; n < NBF; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[n][e] = s2[n][e] = 0.f;
+
+    // ---- staging.  Loads are branch-free (out-of-image lanes read the image's first bytes and are zeroed by an AND
+    // in stash(): a select lets hipcc branch around each load and serialise them); the next tile's loads are issued
+    // before the MFMA phase of this one and written to LDS after it (register prefetch, single LDS buffer).
+    uint4 pv[NPV];
+    unsigned okbits = 0;                                        // bit j: vector j of the fetched tile is inside the image
+    int fb = 0, foy0 = 0, fox0 = 0;                             // image / output origin of the fetched tile
+    auto fetch = [&](int t) {
+        const int b = fastdiv(t, tiles, a.inv_tiles), tl = t - b * tiles;
+        const int ty = fastdiv(tl, a.tiles_x, a.inv_tx), tx = tl - ty * a.tiles_x;
+        const int oy0 = ty * a.R, ox0 = tx * a.CW;
+        fb = b; foy0 = oy0; fox0 = ox0;
+        const int org = (oy0 * a.IW + ox0) * a.Cin;
+        const T* xt = x + (long)b * a.IH * a.IW * a.Cin + org;  // top-left input pixel of the tile
+        okbits = 0;
+#pragma unroll
+        for (int j = 0; j < NPV; ++j) {
+            const bool ok = (unsigned)(oy0 + (pyx[j] >> 16)) < (unsigned)a.IH &&
+                            (unsigned)(ox0 - 64 + (pyx[j] & 0xFFFF)) < (unsigned)a.IW;
+            okbits |= ok ? (1u << j) : 0u;
+            pv[j] = *reinterpret_cast<const uint4*>(xt + (ok ? prel[j] : -org));
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPV; ++j) {
+            const int i = tid + j * 256;
+            const unsigned m = (unsigned)(-(int)((okbits >> j) & 1u));
+            const uint4 t = make_uint4(pv[j].x & m, pv[j].y & m, pv[j].z & m, pv[j].w & m);
+            if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + (i / VPP) * PXB + (i % VPP) * 16) = t;
+        }
+    };
+
+    fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        stash();
+        __syncthreads();
+        const int cb = fb, coy0 = foy0, cox0 = fox0;            // the tile being computed
+        if (t + (int)gridDim.x < total) fetch(t + gridDim.x);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int n = 0; n < NBF; ++n) acc[f][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- MFMA over 9 taps x CK channels
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int k0 = s * KC + q * VEC;
+            int tap = k0 / CK;
+            const int c = k0 % CK;
+            tap = tap > 8 ? 8 : tap;  // padded k: weights are zero there, read any finite data
+            const int toff = ((tap / 3) * PW + (tap % 3)) * PXB + c * (int)sizeof(T);
+            uint4 fw[NBF], fp[4];
+#pragma unroll
+            for (int n = 0; n < NBF; ++n)
+                fw[n] = *reinterpret_cast<const uint4*>(wl + (n * 16 + r) * WROWB + k0 * (int)sizeof(T));
+#pragma unroll
+            for (int f = 0; f < 4; ++f) fp[f] = *reinterpret_cast<const uint4*>(patch + pbase[f] + toff);
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int n = 0; n < NBF; ++n) Mma<T>::mma(acc[f][n], fw[n], fp[f]);
+        }
+        // ---- epilogue: + bias, store (lane owns 4 consecutive channels of one pixel), BN partial statistics
+        T* yt = y + ((long)(cb * a.OH + coy0) * a.OW + cox0) * a.Cout + co0 + q * 4;
+#pragma unroll
+        for (int n = 0; n < NBF; ++n) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(biasl + n * 16 + q * 4);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int pr = frc[f] >> 16, pc = frc[f] & 0xFFFF;
+                const bool ok = coy0 + pr < a.OH && cox0 + pc < a.OW;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = to_f32(from_f32<T>(acc[f][n][e] + bv[e]));  // statistics of what is stored
+                    const float vs = ok ? v[e] : 0.f;
+                    s1[n][e] += vs;
+                    s2[n][e] += vs * vs;
+                }
+                if (ok) store_vec4<T>(yt + (pr * a.OW + pc) * a.Cout + n * 16, v);
+            }
+        }
+        __syncthreads();
+    }
+
+    if (a.stats) {
+        float* red = reinterpret_cast<float*>(smem);  // [4 waves][NB][2]; staging LDS is free after the last sync
+#pragma unroll
+        for (int n = 0; n < NBF; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t1 = sum16(s1[n][e]), t2 = sum16(s2[n][e]);
+                if (r == 0) {
+                    red[(wave * NB + n * 16 + q * 4 + e) * 2 + 0] = t1;
+                    red[(wave * NB + n * 16 + q * 4 + e) * 2 + 1] = t2;
+                }
+            }
+        __syncthreads();
+        if (tid < NB * 2) {
+            const float tt = red[tid] + red[NB * 2 + tid] + red[2 * NB * 2 + tid] + red[3 * NB * 2 + tid];
+            a.stats[((long)blockIdx.x * a.Cout + co0) * 2 + tid] = tt;
+        }
+    }
+}
+
+// LDS of either variant (the persistent one adds the resident bias row)
+template <typename T, int CK, int NBF>
+size_t igemm_lds(const ConvArgs& a) {
     using Cfg = ConvCfg<T, CK>;
     const int PPIX = (a.R + 2) * (a.CW + 2);
-    size_t lds = (size_t)(PPIX * Cfg::PXB + 15) / 16 * 16 + (size_t)NBF * 16 * Cfg::WROWB;
+    size_t lds = (size_t)(PPIX * Cfg::PXB + 15) / 16 * 16 + (size_t)NBF * 16 * Cfg::WROWB + (size_t)NBF * 16 * 4;
     if (lds < (size_t)4 * NBF * 16 * 2 * sizeof(float)) lds = (size_t)4 * NBF * 16 * 2 * sizeof(float);
-    if (lds > 160 * 1024) return VQA_ERR_ARG;
-    dim3 grid(a.tiles_x * a.tiles_y, a.B, a.Cout / (NBF * 16));
-    auto k = conv3x3_igemm<T, CK, NBF>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+    return lds;
+}
+
+// plan_only: returns G = rows of the statistics buffer = workgroups per output-channel block.
+//   single chunk (Cin == CK): persistent kernel, G = resident workgroups (occupancy x 256 CUs) / channel blocks
+//   multi chunk:              one workgroup per (tile, image), G = tiles * B
+template <typename T, int CK, int NBF>
+int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
+    const size_t lds = igemm_lds<T, CK, NBF>(a);
+    const int total = a.tiles_x * a.tiles_y * a.B, zb = a.Cout / (NBF * 16);
+    if (lds > 160 * 1024) return plan_only ? -1 : VQA_ERR_ARG;
+    const bool persistent = a.Cin == CK;
+    auto kp = conv3x3_igemm_p<T, CK, NBF>;
+    auto kt = conv3x3_igemm_tile<T, CK, NBF>;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(persistent ? (const void*)kp : (const void*)kt,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (plan_only) {
+        if (!persistent) return total;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kp, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        int g = (256 * per_cu) / zb;
+        if (g < 1) g = 1;
+        return g < total ? g : total;
+    }
+    if (persistent) {
+        if (G < 1 || G > total) return VQA_ERR_ARG;
+        hipLaunchKernelGGL(kp, dim3(G, zb), dim3(256), lds, s, a);
+    } else {
+        if (G != total) return VQA_ERR_ARG;
+        hipLaunchKernelGGL(kt, dim3(a.tiles_x * a.tiles_y, a.B, zb), dim3(256), lds, s, a);
+    }
     CHECK_LAUNCH();
     return VQA_OK;
 }
 
 template <typename T, int CK>
-int dispatch_nb(hipStream_t s, const ConvArgs& a) {
-    if (a.Cout % 64 == 0) return launch_igemm<T, CK, 4>(s, a);
-    if (a.Cout == 32) return launch_igemm<T, CK, 2>(s, a);
-    if (a.Cout == 16) return launch_igemm<T, CK, 1>(s, a);
-    return VQA_ERR_ARG;
+int dispatch_nb(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
+    if (a.Cout % 64 == 0) return launch_igemm<T, CK, 4>(s, a, G, plan_only);
+    if (a.Cout == 32) return launch_igemm<T, CK, 2>(s, a, G, plan_only);
+    if (a.Cout == 16) return launch_igemm<T, CK, 1>(s, a, G, plan_only);
+    return plan_only ? -1 : VQA_ERR_ARG;
 }
 
 // ---------------------------------------------------------------------------------------------- wgrad
@@ -512,27 +716,37 @@ __global__ void nchw_to_nhwc(const TI* in, T* out, int B, int C, int H, int W, i
 
 }  // namespace
 
-extern "C" int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked, void* y,
-                               const float* bias, float* stats, int B, int IH, int IW, int Cin, int OH, int OW,
-                               int Cout, int pad, int R, int CW) {
+static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* wpacked, void* y, const float* bias,
+                          float* stats, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW,
+                          int G, bool plan_only) {
+    const int bad = plan_only ? -1 : VQA_ERR_ARG;
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || R * CW > 256 ||
-        (R + 2) * (CW + 2) > 384)
-        return VQA_ERR_ARG;
-    ConvArgs a{x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, (OW + CW - 1) / CW,
-               (OH + R - 1) / R, 1.0f / CW, 1.0f / (CW + 2), 1.0f / ((OW + CW - 1) / CW)};
-    hipStream_t s = static_cast<hipStream_t>(stream);
+        (R + 2) * (CW + 2) > 384 || B < 1)
+        return bad;
+    const int tx_ = (OW + CW - 1) / CW, ty_ = (OH + R - 1) / R;
+    ConvArgs a{x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
+               1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_)};
     if (dtype == VQA_BF16) {
-        if (Cin % 32 == 0) return dispatch_nb<bf16, 32>(s, a);
-        if (Cin == 16) return dispatch_nb<bf16, 16>(s, a);
+        if (Cin % 32 == 0) return dispatch_nb<bf16, 32>(s, a, G, plan_only);
+        if (Cin == 16) return dispatch_nb<bf16, 16>(s, a, G, plan_only);
     } else if (dtype == VQA_F32) {
-        if (Cin % 16 == 0) return dispatch_nb<float, 16>(s, a);
+        if (Cin % 16 == 0) return dispatch_nb<float, 16>(s, a, G, plan_only);
     }
-    return VQA_ERR_ARG;
+    return bad;
 }
 
-// number of tile blocks the forward writes statistics for (rows of `stats`)
-extern "C" int vqa_conv3x3_stat_rows(int B, int OH, int OW, int R, int CW) {
-    return B * ((OW + CW - 1) / CW) * ((OH + R - 1) / R);
+extern "C" int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked, void* y,
+                               const float* bias, float* stats, int B, int IH, int IW, int Cin, int OH, int OW,
+                               int Cout, int pad, int R, int CW, int G) {
+    return conv_fwd_entry(static_cast<hipStream_t>(stream), dtype, x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW,
+                          Cout, pad, R, CW, G, false);
+}
+
+// G for vqa_conv3x3_fwd: persistent workgroups per output-channel block = rows of `stats`; -1 = unsupported shape
+extern "C" int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R,
+                                int CW) {
+    return conv_fwd_entry(nullptr, dtype, nullptr, nullptr, nullptr, nullptr, nullptr, B, IH, IW, Cin, OH, OW, Cout,
+                          pad, R, CW, 0, true);
 }
 
 extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const void* dy, float* part, float* dw,

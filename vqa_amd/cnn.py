@@ -149,12 +149,12 @@ def first_fwd(images, w, bias, pad, want_stats):
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
     R, CW = pick_tile(OH, OW)
     y = torch.empty(B, OH, OW, 16, device=images.device, dtype=torch.bfloat16)
-    stats = None
-    if want_stats:
-        stats = torch.empty(B * (-(-OH // R)) * (-(-OW // CW)), 16, 2, device=images.device, dtype=torch.float32)
+    G = min(B * (-(-OH // R)) * (-(-OW // CW)), 256 * 4)      # persistent workgroups: 4 resident per CU
+    stats = torch.empty(G, 16, 2, device=images.device, dtype=torch.float32) if want_stats else None
     tag = dict(kind='first', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
                bytes=float(images.numel() * images.element_size() + y.numel() * 2 + w.numel() * 4))
-    L.call('vqa_conv3x3_first_fwd', L.dt(images), images, w, y, bias, stats, B, IH, IW, OH, OW, pad, R, CW, tag=tag)
+    L.call('vqa_conv3x3_first_fwd', L.dt(images), images, w, y, bias, stats, B, IH, IW, OH, OW, pad, R, CW, G,
+           tag=tag)
     return y, stats
 
 
@@ -163,7 +163,7 @@ def first_wgrad(images, dy, pad):
     _, OH, OW, _ = dy.shape
     R, CW = pick_tile(OH, OW)
     tiles = B * (-(-OH // R)) * (-(-OW // CW))
-    G = min(tiles, 256 * 6)
+    G = min(tiles, 256 * 5)
     part = torch.empty(G, 16, 32, device=dy.device, dtype=torch.float32)
     dw = torch.empty(16, 3, 3, 3, device=dy.device, dtype=torch.float32)
     tag = dict(kind='first_wgrad', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,

@@ -26,30 +26,50 @@ constexpr int NIV = (3 * PMAX + 255) / 256;     // image elements per thread per
 
 template <typename TI> __device__ __forceinline__ float ld_f32(const TI* p) { return (float)*p; }
 
-// Branch-free image patch fetch: element i = (c, py, px) of the 3 x (R+2) x (CW+2) patch of tile (b, oy0, ox0).
-template <typename TI>
-__device__ __forceinline__ void fetch_patch(const FirstArgs& a, const TI* img, int b, int oy0, int ox0, int PW, int PP,
-                                            float inv_pp, bf16 (&v)[NIV]) {
+// Both kernels are persistent: workgroup g walks the (image, tile) pairs t = g, g + G, ...; what does not depend on the
+// tile is computed once per workgroup (a wave64 VALU instruction costs its SIMD 4 cycles, and per-tile index
+// arithmetic is what these HBM-bound kernels spend their time on otherwise).
+struct PatchPlan {           // per thread: the NIV patch elements (c, py, px) it stages
+    int rel[NIV];            // c*IH*IW + (py-pad)*IW + (px-pad): offset from the tile's top-left input pixel
+    int pyx[NIV];            // (py-pad) << 16 | (px-pad+64); "never inside" rows for elements beyond the patch
+};
+
+__device__ __forceinline__ void plan_patch(const FirstArgs& a, int PW, int PP, PatchPlan& pl) {
     const int tid = threadIdx.x;
+    const float inv_pp = 1.0f / PP;
 #pragma unroll
     for (int j = 0; j < NIV; ++j) {
         const int i = tid + j * 256;
         const int c = fastdiv(i, PP, inv_pp), rem = i - c * PP;
         const int py = fastdiv(rem, PW, a.inv_pw), px = rem - py * PW;
-        const int iy = oy0 + py - a.pad, ix = ox0 + px - a.pad;
-        const bool ok = c < 3 && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
-        const long off = ok ? ((long)(b * 3 + c) * a.IH + iy) * a.IW + ix : 0;
-        const float f = ld_f32(img + off);
-        v[j] = (bf16)(ok ? f : 0.f);
+        pl.rel[j] = c * a.IH * a.IW + (py - a.pad) * a.IW + (px - a.pad);
+        pl.pyx[j] = ((c < 3 ? py - a.pad : -0x4000) << 16) | (px - a.pad + 64);
     }
 }
 
-__device__ __forceinline__ void stash_patch(unsigned char* patch, int n, const bf16 (&v)[NIV]) {
+// Branch-free fetch of tile (b, oy0, ox0): all NIV loads in flight together; out-of-image elements read the image's
+// first element and are zeroed in stash_patch (okbits).
+template <typename TI>
+__device__ __forceinline__ void fetch_patch(const FirstArgs& a, const TI* img, const PatchPlan& pl, int b, int oy0,
+                                            int ox0, float (&v)[NIV], unsigned& okbits) {
+    const int org = oy0 * a.IW + ox0;
+    const TI* it = img + (long)b * 3 * a.IH * a.IW + org;
+    okbits = 0;
+#pragma unroll
+    for (int j = 0; j < NIV; ++j) {
+        const bool ok = (unsigned)(oy0 + (pl.pyx[j] >> 16)) < (unsigned)a.IH &&
+                        (unsigned)(ox0 - 64 + (pl.pyx[j] & 0xFFFF)) < (unsigned)a.IW;
+        okbits |= ok ? (1u << j) : 0u;
+        v[j] = ld_f32(it + (ok ? pl.rel[j] : -org));
+    }
+}
+
+__device__ __forceinline__ void stash_patch(unsigned char* patch, int n, const float (&v)[NIV], unsigned okbits) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < NIV; ++j) {
         const int i = tid + j * 256;
-        const bf16 t = v[j];
+        const bf16 t = (bf16)(((okbits >> j) & 1u) ? v[j] : 0.f);
         if (i < n) reinterpret_cast<bf16*>(patch)[i] = t;
     }
 }
@@ -67,14 +87,12 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
     const int PW = a.CW + 2, PP = (a.R + 2) * PW, MT = a.R * a.CW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int tile = blockIdx.x, b = blockIdx.y;
-    const int ty = fastdiv(tile, a.tiles_x, a.inv_tx), tx = tile - ty * a.tiles_x;
-    const int oy0 = ty * a.R, ox0 = tx * a.CW;
+    const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
     const TI* img = static_cast<const TI*>(a.img);
+    if ((int)blockIdx.x >= total) return;
 
-    bf16 pv[NIV];
-    fetch_patch<TI>(a, img, b, oy0, ox0, PW, PP, 1.0f / PP, pv);
-
+    PatchPlan pl;
+    plan_patch(a, PW, PP, pl);
     // weight fragment (MFMA A operand: row = output channel r, k = 8q..8q+7), straight from the f32 master
     bf16x8 fw;
 #pragma unroll
@@ -86,57 +104,80 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
     int koff[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) koff[j] = gather_off(8 * q + j, PW, PP) * 2;
-
-    stash_patch(smem, 3 * PP, pv);
-    __syncthreads();
-
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = a.bias ? a.bias[q * 4 + e] : 0.f;
+    // fragment pixel decode: fragment f of this wave = tile pixels (wave*4+f)*16 + r
+    int pbase[4], frc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int m = (wave * 4 + f) * 16 + r;
+        int pr = 0, pc = 0;
+        if (m < MT) { pr = fastdiv(m, a.CW, a.inv_cw); pc = m - pr * a.CW; }
+        pbase[f] = (pr * PW + pc) * 2;
+        frc[f] = ((m < MT ? pr : 0x4000) << 16) | pc;
+    }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = a.bias[q * 4 + e];
-    }
-    // Fragments in pairs: after the MFMA a lane holds 4 channels (8 bytes) of one pixel per fragment.  One
-    // v_permlane16_swap per dword between the fragments of a pair leaves every lane with 8 consecutive channels
-    // (16 bytes) of ONE pixel - even lane groups the pair's first fragment, odd groups the second - so the tile is
-    // written with half as many, twice as wide stores.
-#pragma unroll
-    for (int fp2 = 0; fp2 < 2; ++fp2) {
-        uint2 pk[2];
-        long opix[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int m = (wave * 4 + fp2 * 2 + h) * 16 + r;
-            int pr = 0, pc = 0;
-            bool ok = m < MT;
-            if (ok) { pr = fastdiv(m, a.CW, a.inv_cw); pc = m - pr * a.CW; }
-            ok = ok && (oy0 + pr < a.OH) && (ox0 + pc < a.OW);
-            opix[h] = ok ? ((long)(b * a.OH + oy0 + pr) * a.OW + ox0 + pc) : -1;
-            const unsigned char* base = smem + (pr * PW + pc) * 2;
-            bf16x8 fp;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) fp[j] = *reinterpret_cast<const bf16*>(base + koff[j]);
-            f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fp, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = (bf16)(acc[e] + bv[e]);
-                const float v = ok ? (float)o[e] : 0.f;          // statistics of what is stored
-                s1[e] += v;
-                s2[e] += v * v;
-            }
-            pk[h] = __builtin_bit_cast(uint2, o);
+
+    float pv[NIV];
+    unsigned okbits;
+    auto tile_org = [&](int t, int& b, int& oy0, int& ox0) {
+        b = fastdiv(t, tiles, a.inv_tiles);
+        const int tl = t - b * tiles, ty = fastdiv(tl, a.tiles_x, a.inv_tx);
+        oy0 = ty * a.R;
+        ox0 = (tl - ty * a.tiles_x) * a.CW;
+    };
+    int fb, foy0, fox0;
+    tile_org(blockIdx.x, fb, foy0, fox0);
+    fetch_patch<TI>(a, img, pl, fb, foy0, fox0, pv, okbits);
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        stash_patch(smem, 3 * PP, pv, okbits);
+        __syncthreads();
+        const int b = fb, oy0 = foy0, ox0 = fox0;
+        if (t + (int)gridDim.x < total) {
+            tile_org(t + gridDim.x, fb, foy0, fox0);
+            fetch_patch<TI>(a, img, pl, fb, foy0, fox0, pv, okbits);
         }
-        auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
-        auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
-        // lane group q now holds channels (q>>1)*8 .. +7 of the pixel of fragment (q&1) of the pair
-        const long op = (q & 1) ? opix[1] : opix[0];
-        if (op >= 0)
-            *reinterpret_cast<uint4*>(a.y + op * 16 + (q >> 1) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        bf16* yt = a.y + ((long)(b * a.OH + oy0) * a.OW + ox0) * 16 + (q >> 1) * 8;
+        // Fragments in pairs: after the MFMA a lane holds 4 channels (8 bytes) of one pixel per fragment.  One
+        // v_permlane16_swap per dword between the fragments of a pair leaves every lane with 8 consecutive channels
+        // (16 bytes) of ONE pixel - even lane groups the pair's first fragment, odd groups the second - so the tile
+        // is written with half as many, twice as wide stores.
+#pragma unroll
+        for (int fp2 = 0; fp2 < 2; ++fp2) {
+            uint2 pk[2];
+            int orel[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int f = fp2 * 2 + h;
+                const int pr = frc[f] >> 16, pc = frc[f] & 0xFFFF;
+                const bool ok = oy0 + pr < a.OH && ox0 + pc < a.OW;
+                orel[h] = ok ? (pr * a.OW + pc) * 16 : -1;
+                const unsigned char* base = smem + pbase[f];
+                bf16x8 fp;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fp[j] = *reinterpret_cast<const bf16*>(base + koff[j]);
+                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fp, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (bf16)(acc[e] + bv[e]);
+                    const float v = ok ? (float)o[e] : 0.f;          // statistics of what is stored
+                    s1[e] += v;
+                    s2[e] += v * v;
+                }
+                pk[h] = __builtin_bit_cast(uint2, o);
+            }
+            auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+            auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+            // lane group q now holds channels (q>>1)*8 .. +7 of the pixel of fragment (q&1) of the pair
+            const int op = (q & 1) ? orel[1] : orel[0];
+            if (op >= 0) *reinterpret_cast<uint4*>(yt + op) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+        __syncthreads();                                      // fragment reads done before the next stash
     }
-    if (a.stats) {
-        __syncthreads();                                  // patch reads done: reuse LDS as [4 waves][16][2]
-        float* red = reinterpret_cast<float*>(smem);
+    if (a.stats) {                                            // one row of partial sums per workgroup
+        float* red = reinterpret_cast<float*>(smem);          // [4 waves][16][2]
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float t1 = sum16(s1[e]), t2 = sum16(s2[e]);
@@ -146,17 +187,14 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
             }
         }
         __syncthreads();
-        if (tid < 32) {
-            const float t = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
-            const long blk = (long)b * gridDim.x + tile;
-            a.stats[blk * 32 + tid] = t;
-        }
+        if (tid < 32) a.stats[(long)blockIdx.x * 32 + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
     }
 }
 
 // Persistent workgroups over (image, tile); the 4 waves split the pixel reduction of a tile.  D rows = output channel
 // (dy fragment by the transposing LDS read), D cols = k index (two 16-column tiles cover k = 0..31), MFMA K = 32
 // pixels with the k <-> pixel map of conv.hip's wgrad: lane group q, element 4h+e <-> pixel ks + 16h + 4q + e.
+// The pixel -> patch offset of every K element is a per-workgroup LDS table (no division in the loop).
 template <typename TI>
 __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -164,69 +202,89 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
     const int MTP = (MT + 31) / 32 * 32;
     unsigned char* patch = smem;
     unsigned char* dyl = smem + (3 * PP * 2 + 15) / 16 * 16;      // [MTP pixels][16 co] bf16, 32 bytes per pixel
+    short* ptab = reinterpret_cast<short*>(dyl + MTP * 32);       // [MTP] byte offset of pixel m inside a patch plane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4, rq = r >> 2, p = r & 3;
     const TI* img = static_cast<const TI*>(a.img);
     const bf16* dy = a.y;
     const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
-    const float inv_pp = 1.0f / PP;
+    if ((int)blockIdx.x >= total) return;
 
-    int koff[2];                                                  // gather offsets of k = r and k = 16 + r
-    koff[0] = gather_off(r, PW, PP) * 2;
-    koff[1] = gather_off(16 + r, PW, PP) * 2;
+    PatchPlan pl;
+    plan_patch(a, PW, PP, pl);
+    // dy vectors of this thread: pixel m = i >> 1, half vv = i & 1
+    int drel[2], drc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + j * 256, m = i >> 1, vv = i & 1;
+        const int pr = fastdiv(m, a.CW, a.inv_cw), pc = m - pr * a.CW;
+        drel[j] = (pr * a.OW + pc) * 16 + vv * 8;
+        drc[j] = ((m < MT ? pr : 0x4000) << 16) | pc;
+    }
+    if (tid < MTP) {
+        const int m = tid < MT ? tid : 0;                         // dy rows beyond the tile are zero: any finite value
+        const int pr = fastdiv(m, a.CW, a.inv_cw);
+        ptab[tid] = (short)((pr * PW + (m - pr * a.CW)) * 2);
+    }
+    const int koff0 = gather_off(r, PW, PP) * 2, koff1 = gather_off(16 + r, PW, PP) * 2;   // k = r and k = 16 + r
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        const int b = fastdiv(t, tiles, a.inv_tiles), tl = t - b * tiles;
-        const int tyy = fastdiv(tl, a.tiles_x, a.inv_tx);
-        const int oy0 = tyy * a.R, ox0 = (tl - tyy * a.tiles_x) * a.CW;
-        bf16 pv[NIV];
-        fetch_patch<TI>(a, img, b, oy0, ox0, PW, PP, inv_pp, pv);
-        uint4 dv[2];
+    auto tile_org = [&](int t, int& b, int& oy0, int& ox0) {
+        b = fastdiv(t, tiles, a.inv_tiles);
+        const int tl = t - b * tiles, ty = fastdiv(tl, a.tiles_x, a.inv_tx);
+        oy0 = ty * a.R;
+        ox0 = (tl - ty * a.tiles_x) * a.CW;
+    };
+    float pv[NIV];
+    uint4 dv[2];
+    unsigned okbits, dok = 0;
+    auto fetch = [&](int t) {
+        int b, oy0, ox0;
+        tile_org(t, b, oy0, ox0);
+        fetch_patch<TI>(a, img, pl, b, oy0, ox0, pv, okbits);
+        const bf16* dt = dy + ((long)(b * a.OH + oy0) * a.OW + ox0) * 16;
+        dok = 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int i = tid + j * 256, m = i >> 1, vv = i & 1;
-            const int pr = fastdiv(m, a.CW, a.inv_cw), pc = m - pr * a.CW;
-            const bool ok = m < MT && oy0 + pr < a.OH && ox0 + pc < a.OW;
-            const long off = ok ? ((long)(b * a.OH + oy0 + pr) * a.OW + ox0 + pc) * 16 + vv * 8 : 0;
-            const uint4 v = *reinterpret_cast<const uint4*>(dy + off);
-            const unsigned msk = ok ? 0xFFFFFFFFu : 0u;
-            dv[j] = make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk);
+            const bool ok = oy0 + (drc[j] >> 16) < a.OH && ox0 + (drc[j] & 0xFFFF) < a.OW;
+            dok |= ok ? (1u << j) : 0u;
+            dv[j] = *reinterpret_cast<const uint4*>(dt + (ok ? drel[j] : 0));
         }
-        __syncthreads();                                          // previous tile's fragment reads are done
-        stash_patch(patch, 3 * PP, pv);
+    };
+    fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        stash_patch(patch, 3 * PP, pv, okbits);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = tid + j * 256;
-            const uint4 tv = dv[j];
+            const unsigned msk = (unsigned)(-(int)((dok >> j) & 1u));
+            const uint4 tv = make_uint4(dv[j].x & msk, dv[j].y & msk, dv[j].z & msk, dv[j].w & msk);
             if (i < MTP * 2) *reinterpret_cast<uint4*>(dyl + i * 16) = tv;
         }
         __syncthreads();
+        if (t + (int)gridDim.x < total) fetch(t + gridDim.x);
         for (int ks = wave * 32; ks < MTP; ks += 128) {
             bf16x8 fa, fb0, fb1;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int m = ks + h * 16 + q * 4 + rq;           // pixel whose dy row this lane addresses
+                const int m0 = ks + h * 16 + q * 4;               // first of the 4 pixels of K elements 4h..4h+3
                 bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(dyl + m * 32 + 4 * p * 2));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fa[4 * h + e] = v[e];
+                    (__attribute__((address_space(3))) bf16x4*)(dyl + (m0 + rq) * 32 + 4 * p * 2));
+                const short4 po = *reinterpret_cast<const short4*>(ptab + m0);
+                const int pof[4] = {po.x, po.y, po.z, po.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    int mm = ks + h * 16 + q * 4 + e;             // pixel of K element 4h+e of this lane group
-                    if (mm >= MT) mm = 0;                         // dy row is zero there: any finite image value
-                    const int pr = fastdiv(mm, a.CW, a.inv_cw);
-                    const unsigned char* base = patch + (pr * PW + (mm - pr * a.CW)) * 2;
-                    fb0[4 * h + e] = *reinterpret_cast<const bf16*>(base + koff[0]);
-                    fb1[4 * h + e] = *reinterpret_cast<const bf16*>(base + koff[1]);
+                    fa[4 * h + e] = v[e];
+                    fb0[4 * h + e] = *reinterpret_cast<const bf16*>(patch + pof[e] + koff0);
+                    fb1[4 * h + e] = *reinterpret_cast<const bf16*>(patch + pof[e] + koff1);
                 }
             }
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb0, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb1, acc[1], 0, 0, 0);
         }
+        __syncthreads();                                          // fragment reads done before the next stash
     }
     // combine the 4 waves (fixed order) and write this workgroup's partial slab [16 co][32 k]
-    __syncthreads();
     float* red = reinterpret_cast<float*>(smem);                  // [3 waves][2][64 lanes][4]
     if (wave > 0) {
 #pragma unroll
@@ -270,12 +328,13 @@ bool first_args(FirstArgs& a, int B, int IH, int IW, int OH, int OW, int pad, in
 
 extern "C" int vqa_conv3x3_first_fwd(void* stream, int in_dtype, const void* images, const float* w, void* y,
                                      const float* bias, float* stats, int B, int IH, int IW, int OH, int OW, int pad,
-                                     int R, int CW) {
+                                     int R, int CW, int G) {
     FirstArgs a{images, w, static_cast<bf16*>(y), bias, stats};
     if (!images || !w || !y || !first_args(a, B, IH, IW, OH, OW, pad, R, CW)) return VQA_ERR_ARG;
+    if (G < 1 || G > a.tiles_x * a.tiles_y * B) return VQA_ERR_ARG;
     size_t lds = (size_t)3 * (R + 2) * (CW + 2) * 2;
     if (lds < 512) lds = 512;
-    dim3 grid(a.tiles_x * a.tiles_y, B);
+    dim3 grid(G);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (in_dtype == VQA_F16) hipLaunchKernelGGL(conv3x3_first_fwd<_Float16>, grid, dim3(256), lds, s, a);
     else if (in_dtype == VQA_F32) hipLaunchKernelGGL(conv3x3_first_fwd<float>, grid, dim3(256), lds, s, a);
@@ -291,7 +350,8 @@ extern "C" int vqa_conv3x3_first_wgrad(void* stream, int in_dtype, const void* i
     FirstArgs a{images, nullptr, static_cast<bf16*>(const_cast<void*>(dy)), nullptr, part};
     if (!images || !dy || !part || !dw || G < 1 || !first_args(a, B, IH, IW, OH, OW, pad, R, CW)) return VQA_ERR_ARG;
     const int MTP = (R * CW + 31) / 32 * 32;
-    size_t lds = (size_t)(3 * (R + 2) * (CW + 2) * 2 + 15) / 16 * 16 + (size_t)MTP * 32;
+    if (G > a.tiles_x * a.tiles_y * B) return VQA_ERR_ARG;
+    size_t lds = (size_t)(3 * (R + 2) * (CW + 2) * 2 + 15) / 16 * 16 + (size_t)MTP * 32 + (size_t)MTP * 2;
     if (lds < 3 * 2 * 64 * 16) lds = 3 * 2 * 64 * 16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (in_dtype == VQA_F16) hipLaunchKernelGGL(conv3x3_first_wgrad<_Float16>, dim3(G), dim3(256), lds, s, a);

@@ -17,12 +17,17 @@ dy = torch.randn(B, OH, OH, cout, device='cuda').to(dt)
 bias = torch.zeros(cout, device='cuda')
 wpk = M.pack_weights(w, cin, dt, False)
 wpk_d = M.pack_weights(w, cin, dt, True)
+img = (torch.randint(0, 256, (B, 3, 224, 224), device='cuda').float() / 255).half()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for it in range(2):
     e0.record()
     for _ in range(reps):
-        if kind == 'fwd':
+        if kind == 'first':
+            M.first_fwd(img, w, bias, pads[0], True)
+        elif kind == 'first_wgrad':
+            M.first_wgrad(img, dy, pads[0])
+        elif kind == 'fwd':
             M.conv_fwd(x, wpk, bias, cout, pads[li], True)
         elif kind == 'dgrad':
             M.conv_fwd(dy, wpk_d, None, cin, 2 - pads[li], False, kind='dgrad')

@@ -19,7 +19,8 @@ def _nhwc(x, dtype):
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 @pytest.mark.parametrize('B,cin,cout,H,W,pad', [(2, 16, 16, 20, 20, 0), (3, 16, 32, 13, 17, 2), (2, 32, 64, 9, 9, 2),
                                                 (1, 64, 64, 30, 30, 0), (2, 128, 256, 14, 14, 0),
-                                                (2, 256, 256, 12, 12, 0), (1, 16, 16, 70, 226, 2)])
+                                                (2, 256, 256, 12, 12, 0), (1, 16, 16, 70, 226, 2), (2, 16, 64, 10, 11, 2),
+                                                (2, 32, 16, 9, 12, 0), (3, 32, 32, 40, 23, 2)])
 def test_conv_fwd_dgrad_wgrad_exact(prec, B, cin, cout, H, W, pad):
     """Small-integer data: every product and sum is exact in bf16/f32, so results must match bit for bit."""
     from vqa_amd import cnn as C

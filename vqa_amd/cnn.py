@@ -101,7 +101,7 @@ def conv_wgrad(x, dy, cin_real, pad):
     B, IH, IW, cin = x.shape
     _, OH, OW, cout = dy.shape
     mt = 256 if x.dtype == torch.bfloat16 else 128
-    R, CW = pick_tile(OH, OW, mt, 512 if mt == 256 else 320)
+    R, CW = pick_tile(OH, OW, mt, 384 if mt == 256 else 320)
     tiles = B * (-(-OH // R)) * (-(-OW // CW))
     ck = _ck(cin, x.dtype)
     pairs = (-(-cout // 64)) * (cin // ck)
@@ -110,9 +110,9 @@ def conv_wgrad(x, dy, cin_real, pad):
     cow = min(cout, 64)                                   # output channels per workgroup (conv.hip dy_stride)
     dyb = (32 if cow == 16 else cow * 2 + 32) if esz == 2 else (64 if cow == 16 else cow * 4 + 64)
     kc = 64 // esz
-    lds = (R + 2) * (CW + 2) * pxb + (-(-R * CW // kc) * kc) * dyb
+    lds = (R + 2) * (CW + 2) * pxb + (-(-R * CW // kc) * kc) * (dyb + 4)
     # resident workgroups per CU: register-limited waves/SIMD of the instantiation, then LDS
-    waves = 2 if ck == 32 else (4 if cow == 16 else 3)
+    waves = 4 if cow == 16 else 2
     per_cu = max(1, min(waves, (160 * 1024) // lds))
     G = max(1, min(tiles, (256 * per_cu) // pairs if pairs <= 256 * per_cu else 1))
     part = torch.empty(G, cout, 9, cin, device=x.device, dtype=torch.float32)

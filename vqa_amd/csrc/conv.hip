@@ -457,152 +457,173 @@ __host__ __device__ constexpr int dy_stride(int esz, int cow) {
     return esz == 2 ? (cow == 16 ? 32 : cow * 2 + 32) : (cow == 16 ? 64 : cow * 4 + 64);
 }
 
+// Wave roles.  A workgroup owns COW output channels x CK input channels x 9 taps = (COW/16) x 9 x (CK/16) MFMA
+// tiles.  Every wave takes ONE 16-input-channel fragment (wcf) and COF = min(2, COW/16) output-channel fragments
+// (wcg), i.e. 9 x COF accumulator tiles; waves left over split the pixel reduction (wk).  Per 32-pixel step a wave
+// then reads 9 patch fragments + COF dy fragments for 9 x COF MFMAs - the patch fragments, which dominate the LDS
+// traffic, are no longer re-read by every output-channel wave.
 template <typename T, int CK, int COW>
 __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     constexpr int VEC = Mma<T>::VEC, KC = 4 * VEC;
     constexpr int PXB = pix_stride(CK * (int)sizeof(T));
     constexpr int DYB = dy_stride((int)sizeof(T), COW);
-    constexpr int nwco = COW / 16, nwk = 4 / nwco;   // waves: (output-channel fragments) x (pixel-reduction slices)
     constexpr int VPP = CK * (int)sizeof(T) / 16;
-    constexpr int CF = CK / 16;  // input-channel fragments
+    constexpr int CF = CK / 16;                         // input-channel fragments of the workgroup
+    constexpr int COF = COW >= 32 ? 2 : 1;              // output-channel fragments per wave
+    constexpr int NCG = COW / 16 / COF;                 // output-channel fragment groups
+    constexpr int nwk = 4 / (CF * NCG);                 // pixel-reduction slices
+    static_assert(CF * NCG * nwk == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int PW = a.CW + 2, PPIX = (a.R + 2) * PW, MT = a.R * a.CW;
     const int MTP = (MT + KC - 1) / KC * KC;
     unsigned char* patch = smem;
     unsigned char* dyl = smem + (PPIX * PXB + 15) / 16 * 16;
+    int* ptab = reinterpret_cast<int*>(dyl + MTP * DYB);   // [MTP] byte offset of tile pixel m inside the patch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int nco = a.Cout / COW;
     const int co0 = (blockIdx.y % nco) * COW, ci0 = (blockIdx.y / nco) * CK;
-    const int wco = wave % nwco, wk = wave / nwco;
+    const int wcf = wave % CF, wcg = (wave / CF) % NCG, wk = wave / (CF * NCG);
     const T* x = static_cast<const T*>(a.x);
     const T* dy = static_cast<const T*>(a.dy);
+    const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
+    if ((int)blockIdx.x >= total) return;
 
-    f32x4 acc[9][CF];
+    f32x4 acc[9][COF];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int c = 0; c < CF; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < COF; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
-    // Software pipeline over pixel tiles: the global loads of tile t+1 are issued into registers before the MFMA
-    // loop of tile t and written to LDS after it, so HBM latency hides under compute even at 1-2 blocks per CU.
-    constexpr int PMAX = sizeof(T) == 2 ? 512 : 320;               // host bound on (R+2)*(CW+2)
+    // ---- once per workgroup: what this thread stages per tile (tile-independent coordinates), pixel -> patch table
+    constexpr int PMAX = sizeof(T) == 2 ? 384 : 320;               // host bound on (R+2)*(CW+2)
     constexpr int dvp = COW / VEC;                                 // 16-byte vectors per dy pixel
     constexpr int dsh = dvp == 16 ? 4 : (dvp == 8 ? 3 : (dvp == 4 ? 2 : 1));
     constexpr int NPV = (PMAX * VPP + 255) / 256;                  // 16-byte vectors per thread: patch,
     constexpr int NDV = (sizeof(T) == 2 ? 256 : 128) * dvp / 256;  // dy tile (MT <= 256 / 128 pixels)
+    int prel[NPV], pyx[NPV], drel[NDV], drc[NDV];
+#pragma unroll
+    for (int j = 0; j < NPV; ++j) {
+        const int i = tid + j * 256;
+        const int px = i / VPP, vv = i % VPP;
+        const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
+        pyx[j] = ((i < PPIX * VPP ? py - a.pad : -0x4000) << 16) | (pxx - a.pad + 64);
+        prel[j] = ((py - a.pad) * a.IW + (pxx - a.pad)) * a.Cin + ci0 + vv * VEC;
+    }
+#pragma unroll
+    for (int j = 0; j < NDV; ++j) {
+        const int i = tid + j * 256, m = i >> dsh, vv = i & (dvp - 1);
+        const int pr = fastdiv(m, a.CW, a.inv_cw), pc = m - pr * a.CW;
+        drc[j] = ((m < MT ? pr : 0x4000) << 16) | pc;
+        drel[j] = (pr * a.OW + pc) * a.Cout + co0 + vv * VEC;
+    }
+    for (int m = tid; m < MTP; m += 256) {
+        const int mm = m < MT ? m : 0;                             // dy rows beyond the tile are zero: any finite x
+        const int pr = fastdiv(mm, a.CW, a.inv_cw);
+        ptab[m] = (pr * PW + (mm - pr * a.CW)) * PXB;
+    }
+
+    // ---- software pipeline over pixel tiles: the (branch-free) global loads of tile t+1 are issued into registers
+    // before the MFMA loop of tile t and written to LDS after it
     uint4 pv[NPV], dv[NDV];
+    unsigned pok = 0, dok = 0;
     auto fetch = [&](int t) {
         const int b = fastdiv(t, tiles, a.inv_tiles), tl = t - b * tiles;
         const int tyy = fastdiv(tl, a.tiles_x, a.inv_tx);
         const int oy0 = tyy * a.R, ox0 = (tl - tyy * a.tiles_x) * a.CW;
+        const int org = (oy0 * a.IW + ox0) * a.Cin;
+        const T* xt = x + (long)b * a.IH * a.IW * a.Cin + org;
+        const T* dt = dy + ((long)(b * a.OH + oy0) * a.OW + ox0) * a.Cout;
+        pok = dok = 0;
 #pragma unroll
         for (int j = 0; j < NPV; ++j) {
-            const int i = tid + j * 256;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (i < PPIX * VPP) {
-                const int px = i / VPP, vv = i % VPP;
-                const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
-                const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
-                if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
-                    v = *reinterpret_cast<const uint4*>(x + ((long)(b * a.IH + iy) * a.IW + ix) * a.Cin + ci0 + vv * VEC);
-            }
-            pv[j] = v;
+            const bool ok = (unsigned)(oy0 + (pyx[j] >> 16)) < (unsigned)a.IH &&
+                            (unsigned)(ox0 - 64 + (pyx[j] & 0xFFFF)) < (unsigned)a.IW;
+            pok |= ok ? (1u << j) : 0u;
+            pv[j] = *reinterpret_cast<const uint4*>(xt + (ok ? prel[j] : -org));
         }
 #pragma unroll
         for (int j = 0; j < NDV; ++j) {
-            const int i = tid + j * 256;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            const int m = i >> dsh, vv = i & (dvp - 1);
-            if (m < MT) {
-                const int pr = fastdiv(m, a.CW, a.inv_cw), pc = m - pr * a.CW;
-                if (oy0 + pr < a.OH && ox0 + pc < a.OW)
-                    v = *reinterpret_cast<const uint4*>(dy + ((long)(b * a.OH + oy0 + pr) * a.OW + ox0 + pc) * a.Cout +
-                                                        co0 + vv * VEC);
-            }
-            dv[j] = v;
+            const bool ok = oy0 + (drc[j] >> 16) < a.OH && ox0 + (drc[j] & 0xFFFF) < a.OW;
+            dok |= ok ? (1u << j) : 0u;
+            dv[j] = *reinterpret_cast<const uint4*>(dt + (ok ? drel[j] : 0));
         }
     };
     auto stash = [&]() {
 #pragma unroll
         for (int j = 0; j < NPV; ++j) {
             const int i = tid + j * 256;
-            if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + (i / VPP) * PXB + (i % VPP) * 16) = pv[j];
+            const unsigned m = (unsigned)(-(int)((pok >> j) & 1u));
+            const uint4 t = make_uint4(pv[j].x & m, pv[j].y & m, pv[j].z & m, pv[j].w & m);
+            if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + (i / VPP) * PXB + (i % VPP) * 16) = t;
         }
 #pragma unroll
         for (int j = 0; j < NDV; ++j) {
             const int i = tid + j * 256;
-            if (i < (MTP << dsh)) *reinterpret_cast<uint4*>(dyl + (i >> dsh) * DYB + (i & (dvp - 1)) * 16) = dv[j];
+            const unsigned m = (unsigned)(-(int)((dok >> j) & 1u));
+            const uint4 t = make_uint4(dv[j].x & m, dv[j].y & m, dv[j].z & m, dv[j].w & m);
+            if (i < (MTP << dsh)) *reinterpret_cast<uint4*>(dyl + (i >> dsh) * DYB + (i & (dvp - 1)) * 16) = t;
         }
     };
-    if ((int)blockIdx.x < total) fetch(blockIdx.x);
+    fetch(blockIdx.x);
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         stash();
         __syncthreads();
         if (t + (int)gridDim.x < total) fetch(t + gridDim.x);
-        {
-            for (int ks = wk * KC; ks < MTP; ks += nwk * KC) {
-                if constexpr (sizeof(T) == 2) {
-                    // bf16: lane i = 4*rq + p of a 16-lane group supplies the address of k-row rq, channels 4p..4p+3;
-                    // it receives channel i of 4 k-rows.  Two reads = the 8 k (pixels) of lane group q.
-                    const int rq = r >> 2, p = r & 3;
-                    uint4 fa;  // dy fragment: rows = co
-                    int poff[2];
-                    {
-                        bf16x4 lo, hi;
+        for (int ks = wk * KC; ks < MTP; ks += nwk * KC) {
+            if constexpr (sizeof(T) == 2) {
+                // bf16: lane i = 4*rq + p of a 16-lane group supplies the address of k-row rq, channels 4p..4p+3;
+                // it receives channel i of 4 k-rows.  Two reads = the 8 k (pixels) of lane group q.
+                // k -> pixel map of the chunk: lane group q, element 4h+e  <->  pixel ks + 16h + 4q + e, so one
+                // read instruction's 32-lane half touches 8 CONSECUTIVE pixels (bank-conflict-free strides)
+                const int rq = r >> 2, p = r & 3;
+                const int m0 = ks + q * 4 + rq, m1 = m0 + 16;
+                uint4 fa[COF];  // dy fragments: rows = co
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            // k -> pixel map of the chunk: lane group q, element 4h+e  <->  pixel ks + 16h + 4q + e, so one
-                            // read instruction's 32-lane half touches 8 CONSECUTIVE pixels (bank-conflict-free strides)
-                            int m = ks + h * 16 + q * 4 + rq;
-                            const unsigned char* ad = dyl + m * DYB + (wco * 16 + 4 * p) * 2;
-                            bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                                (__attribute__((address_space(3))) bf16x4*)(ad));
-                            if (h == 0) lo = v; else hi = v;
-                            if (m >= MT) m = 0;
-                            const int pr = fastdiv(m, a.CW, a.inv_cw);
-                            poff[h] = (pr * PW + (m - pr * a.CW)) * PXB + 4 * p * 2;
-                        }
-                        bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        fa = __builtin_bit_cast(uint4, f);
-                    }
+                for (int c = 0; c < COF; ++c) {
+                    const unsigned char* ad = dyl + ((wcg * COF + c) * 16 + 4 * p) * 2;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(ad + m0 * DYB));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(ad + m1 * DYB));
+                    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    fa[c] = __builtin_bit_cast(uint4, f);
+                }
+                const unsigned char* b0 = patch + ptab[m0] + 4 * p * 2 + wcf * 32;
+                const unsigned char* b1 = patch + ptab[m1] + 4 * p * 2 + wcf * 32;
 #pragma unroll
-                    for (int tp = 0; tp < 9; ++tp) {
-                        const int toff = ((tp / 3) * PW + (tp % 3)) * PXB;
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int toff = ((tp / 3) * PW + (tp % 3)) * PXB;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(b0 + toff));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(b1 + toff));
+                    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-                        for (int c = 0; c < CF; ++c) {
-                            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                                (__attribute__((address_space(3))) bf16x4*)(patch + poff[0] + toff + c * 32));
-                            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                                (__attribute__((address_space(3))) bf16x4*)(patch + poff[1] + toff + c * 32));
-                            bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            Mma<T>::mma(acc[tp][c], fa, __builtin_bit_cast(uint4, f));
-                        }
-                    }
-                } else {
-                    // f32: MFMA j of the chunk takes pixel k = ks + 4j + q
-                    float fa[4];
-                    int poff[4];
+                    for (int c = 0; c < COF; ++c) Mma<T>::mma(acc[tp][c], fa[c], __builtin_bit_cast(uint4, f));
+                }
+            } else {
+                // f32: MFMA j of the chunk takes pixel k = ks + 4j + q
+                float fa[COF][4];
+                const unsigned char* bp[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = ks + 4 * j + q;
+#pragma unroll
+                    for (int c = 0; c < COF; ++c)
+                        fa[c][j] = *reinterpret_cast<const float*>(dyl + m * DYB + ((wcg * COF + c) * 16 + r) * 4);
+                    bp[j] = patch + ptab[m] + r * 4 + wcf * 64;
+                }
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int toff = ((tp / 3) * PW + (tp % 3)) * PXB;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        int m = ks + 4 * j + q;
-                        fa[j] = *reinterpret_cast<const float*>(dyl + m * DYB + (wco * 16 + r) * 4);
-                        if (m >= MT) m = 0;
-                        const int pr = fastdiv(m, a.CW, a.inv_cw);
-                        poff[j] = (pr * PW + (m - pr * a.CW)) * PXB + r * 4;
-                    }
+                        const float fb = *reinterpret_cast<const float*>(bp[j] + toff);
 #pragma unroll
-                    for (int tp = 0; tp < 9; ++tp) {
-                        const int toff = ((tp / 3) * PW + (tp % 3)) * PXB;
-#pragma unroll
-                        for (int c = 0; c < CF; ++c)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float fb = *reinterpret_cast<const float*>(patch + poff[j] + toff + c * 64);
-                                acc[tp][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb, acc[tp][c], 0, 0, 0);
-                            }
+                        for (int c = 0; c < COF; ++c)
+                            acc[tp][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c][j], fb, acc[tp][c], 0, 0, 0);
                     }
                 }
             }
@@ -612,22 +633,23 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     // combine the pixel slices of the block in LDS (fixed order), then one partial slab per workgroup
     if constexpr (nwk > 1) {
         float* red = reinterpret_cast<float*>(smem);   // staging LDS is free after the loop's last barrier
+        const int wl = wave % (CF * NCG);              // this wave's role inside its slice
         if (wk > 0) {
-            float* dst = red + ((long)((wk - 1) * nwco + wco) * 9 * CF) * 256 + lane * 4;
+            float* dst = red + ((long)((wk - 1) * (CF * NCG) + wl) * 9 * COF) * 256 + lane * 4;
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-                for (int c = 0; c < CF; ++c)
-                    *reinterpret_cast<f32x4*>(dst + (tp * CF + c) * 256) = acc[tp][c];
+                for (int c = 0; c < COF; ++c)
+                    *reinterpret_cast<f32x4*>(dst + (tp * COF + c) * 256) = acc[tp][c];
         }
         __syncthreads();
         if (wk == 0) {
             for (int k = 1; k < nwk; ++k) {
-                const float* src = red + ((long)((k - 1) * nwco + wco) * 9 * CF) * 256 + lane * 4;
+                const float* src = red + ((long)((k - 1) * (CF * NCG) + wl) * 9 * COF) * 256 + lane * 4;
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-                    for (int c = 0; c < CF; ++c) acc[tp][c] += *reinterpret_cast<const f32x4*>(src + (tp * CF + c) * 256);
+                    for (int c = 0; c < COF; ++c) acc[tp][c] += *reinterpret_cast<const f32x4*>(src + (tp * COF + c) * 256);
             }
         }
     }
@@ -636,10 +658,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-            for (int c = 0; c < CF; ++c)
+            for (int c = 0; c < COF; ++c)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int co = co0 + wco * 16 + q * 4 + e, ci = ci0 + c * 16 + r;
+                    const int co = co0 + (wcg * COF + c) * 16 + q * 4 + e, ci = ci0 + wcf * 16 + r;
                     a.part[(((long)blockIdx.x * a.Cout + co) * 9 + tp) * a.Cin + ci] = acc[tp][c][e];
                 }
     }
@@ -756,7 +778,6 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     const int tx_ = (OW + CW - 1) / CW, ty_ = (OH + R - 1) / R;
     const int COW = Cout >= 64 ? 64 : Cout;      // output channels per workgroup
     if ((COW != 16 && COW != 32 && COW != 64) || Cout % COW) return VQA_ERR_ARG;
-    const int nwk = 64 / COW;
     WgradArgs a{x, dy, part, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
                 1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_)};
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -765,8 +786,10 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     auto go = [&](auto kern, int CK, int esz) {
         const int KC = 64 / esz;
         const int MTP = (MT + KC - 1) / KC * KC;
-        size_t lds = (size_t)(PPIX * pix_stride(CK * esz) + 15) / 16 * 16 + (size_t)MTP * dy_stride(esz, COW);
-        const size_t red = (size_t)(nwk - 1) * (4 / nwk) * 9 * (CK / 16) * 1024;   // cross-slice combine buffer
+        size_t lds = (size_t)(PPIX * pix_stride(CK * esz) + 15) / 16 * 16 + (size_t)MTP * dy_stride(esz, COW) +
+                     (size_t)MTP * 4;                                                // + pixel -> patch table
+        const int cof = COW >= 32 ? 2 : 1, roles = (CK / 16) * (COW / 16 / cof), nwk = 4 / roles;
+        const size_t red = (size_t)(nwk - 1) * roles * 9 * cof * 1024;              // cross-slice combine buffer
         if (lds < red) lds = red;
         if (lds > 160 * 1024) return VQA_ERR_ARG;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -775,7 +798,7 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
         return hipGetLastError() == hipSuccess ? VQA_OK : VQA_ERR_LAUNCH;
     };
     if (dtype == VQA_BF16) {
-        if (MT > 256 || PPIX > 512) return VQA_ERR_ARG;
+        if (MT > 256 || PPIX > 384) return VQA_ERR_ARG;
 #define GO_COW(T, CK, ESZ)                                                       \
     (COW == 64 ? go(conv3x3_wgrad<T, CK, 64>, CK, ESZ)                           \
                : (COW == 32 ? go(conv3x3_wgrad<T, CK, 32>, CK, ESZ) : go(conv3x3_wgrad<T, CK, 16>, CK, ESZ)))

@@ -668,25 +668,48 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
 }
 
 // dW[co][ci][tap] (torch layout, ci < Cin_real) = sum_g part[g][co][tap][ci], fixed summation order.
-// 256 threads = OPB outputs x TPO partial-lanes; TPO grows as the output count shrinks so that small layers
-// (2304 outputs, hundreds of partials) still fill the chip.
+// 256 threads = (OPB/4 lanes, each 4 consecutive outputs = one 16-byte load per partial slab) x TPO partial-lanes;
+// TPO grows as the output count shrinks so that small layers (2304 outputs, hundreds of partials) still fill the
+// chip while every slab row is read in contiguous 16-byte pieces.
 template <int TPO>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce(const float* part, float* dw, int G, int Cout, int Cin,
                                                             int Cin_real) {
-    constexpr int OPB = 256 / TPO;
-    __shared__ float red[256];
-    const int n = Cout * 9 * Cin;
-    const int ol = threadIdx.x % OPB, gl = threadIdx.x / OPB;
-    const int i = blockIdx.x * OPB + ol;
-    float s = 0.f;
-    if (i < n)
-        for (int g = gl; g < G; g += TPO) s += part[(long)g * n + i];
+    constexpr int OL = 256 / TPO, OPB = OL * 4;     // output lanes, outputs per block
+    __shared__ float4 red[256];
+    const int n = Cout * 9 * Cin;                   // multiple of 16
+    const int ol = threadIdx.x % OL, gl = threadIdx.x / OL;
+    const int i = blockIdx.x * OPB + ol * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        const float* p = part + i;
+        int g = gl;
+        for (; g + 3 * TPO < G; g += 4 * TPO) {     // 4 independent loads in flight
+            const float4 a0 = *reinterpret_cast<const float4*>(p + (long)g * n);
+            const float4 a1 = *reinterpret_cast<const float4*>(p + (long)(g + TPO) * n);
+            const float4 a2 = *reinterpret_cast<const float4*>(p + (long)(g + 2 * TPO) * n);
+            const float4 a3 = *reinterpret_cast<const float4*>(p + (long)(g + 3 * TPO) * n);
+            s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
+            s.x += a1.x; s.y += a1.y; s.z += a1.z; s.w += a1.w;
+            s.x += a2.x; s.y += a2.y; s.z += a2.z; s.w += a2.w;
+            s.x += a3.x; s.y += a3.y; s.z += a3.z; s.w += a3.w;
+        }
+        for (; g < G; g += TPO) {
+            const float4 a0 = *reinterpret_cast<const float4*>(p + (long)g * n);
+            s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
+        }
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     if (gl == 0 && i < n) {
-        for (int k = 1; k < TPO; ++k) s += red[k * OPB + ol];
-        const int ci = i % Cin, tp = (i / Cin) % 9, co = i / (9 * Cin);
-        if (ci < Cin_real) dw[((long)co * Cin_real + ci) * 9 + tp] = s;
+        for (int k = 1; k < TPO; ++k) {
+            const float4 t = red[k * OL + ol];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        const float v[4] = {s.x, s.y, s.z, s.w};
+        const int ci0 = i % Cin, tp = (i / Cin) % 9, co = i / (9 * Cin);   // 4 consecutive ci of one (co, tap)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (ci0 + e < Cin_real) dw[((long)co * Cin_real + ci0 + e) * 9 + tp] = v[e];
     }
 }
 
@@ -811,12 +834,12 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     }
     if (status != VQA_OK) return status;
     const int n = Cout * 9 * Cin;
-    if (n >= 262144 || G <= 4)
-        hipLaunchKernelGGL(conv3x3_wgrad_reduce<4>, dim3((n + 63) / 64), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
-    else if (n >= 32768 || G <= 16)
-        hipLaunchKernelGGL(conv3x3_wgrad_reduce<16>, dim3((n + 15) / 16), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
+    if (n >= 524288 || G <= 4)
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<4>, dim3((n + 255) / 256), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
+    else if (n >= 65536 || G <= 16)
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<16>, dim3((n + 63) / 64), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
     else
-        hipLaunchKernelGGL(conv3x3_wgrad_reduce<64>, dim3((n + 3) / 4), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<64>, dim3((n + 15) / 16), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
     CHECK_LAUNCH();
     return VQA_OK;
 }

@@ -30,6 +30,10 @@ int vqa_nchw_to_nhwc(void* stream, int in_dtype, int out_dtype, const void* in, 
 int vqa_conv_pack(void* stream, int dtype, const float* w, void* out, int Cout, int Cin, int CinP, int CK, int KP,
                   int dgrad);
 
+/* The same for n (<= 24) weights in one launch: w / out are HOST arrays of device pointers, desc a host array of
+ * n x 6 ints (Cout, Cin, CinP, CK, KP, dgrad). */
+int vqa_conv_pack_all(void* stream, int dtype, int n, const void* const* w, void* const* out, const int* desc);
+
 /* nn.Conv2d(k=3, stride 1, padding=pad) forward (cnn.py:23-40) as implicit GEMM on MFMA; also the data gradient
  * when called on dy with a dgrad slab and pad' = 2 - pad.  y = conv(x) + bias.  R x CW (<= 256 pixels) is the output
  * tile; G persistent workgroups per output-channel block walk the (image, tile) pairs - take G from
@@ -57,10 +61,10 @@ int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const void* dy, fl
 
 /* nn.BatchNorm2d training statistics (cnn.py:23-40; eps 1e-5, momentum 0.1): from the conv partials to mean,
  * invstd, scale = gamma*invstd, shift = beta - mean*scale; running_mean / running_var updated in place
- * (unbiased variance); running_* may be NULL.  slab = scratch of 32*C*2 doubles (two-stage fixed-order sum). */
+ * (unbiased variance); running_* may be NULL.  The `rows` partial rows are summed in fp64 in a fixed order. */
 int vqa_bn_finalize(void* stream, const float* part, int rows, int C, double count, const float* gamma,
                     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                    float* mean, float* invstd, float* scale, float* shift, double* slab);
+                    float* mean, float* invstd, float* scale, float* shift);
 /* eval-mode BatchNorm2d: scale / shift from the running statistics. */
 int vqa_bn_eval_coeffs(void* stream, int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift);

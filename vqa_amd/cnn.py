@@ -62,6 +62,31 @@ def pack_weights(w, cin_p, dtype, dgrad):
     return out
 
 
+def pack_all(jobs, dtype):
+    """jobs = [(w, cin_p, dgrad)]: every slab of the step in ONE launch; returns the slabs (views of one buffer)."""
+    if not jobs:
+        return []
+    ct = L.ctypes
+    desc, sizes = [], []
+    for w, cin_p, dgrad in jobs:
+        cout, cin = w.shape[0], w.shape[1]
+        red, rows = (cout, cin_p) if dgrad else (cin_p, cout)
+        ck = _ck(red, dtype)
+        kp = _kp(ck, dtype)
+        desc += [cout, cin, cin_p, ck, kp, int(dgrad)]
+        sizes.append(-(-(red // ck) * rows * kp // 64) * 64)          # 128-byte aligned slices
+    buf = torch.empty(sum(sizes), device=jobs[0][0].device, dtype=dtype)
+    outs, off = [], 0
+    for n in sizes:
+        outs.append(buf[off:off + n])
+        off += n
+    n = len(jobs)
+    L.check(L.lib().vqa_conv_pack_all(L.stream(), L.dt(buf), n, (ct.c_void_p * n)(*[j[0].data_ptr() for j in jobs]),
+                                      (ct.c_void_p * n)(*[o.data_ptr() for o in outs]), (ct.c_int * (6 * n))(*desc)),
+            'vqa_conv_pack_all')
+    return outs
+
+
 def _conv_tag(kind, B, OH, OW, cin_real, cout_real, x, y_elems_bytes, w_bytes):
     """Algorithmic work of one conv launch for bench.py's roofline leg: MACs as the reference writes them
     (real channel counts), bytes = input read once + output written once + weights."""
@@ -172,24 +197,23 @@ def first_wgrad(images, dy, pad):
     return dw
 
 
-def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False):
+def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False, wpk=None):
     """conv3x3 -> BatchNorm -> ReLU -> (pool).  x NHWC (first=True: the NCHW image, dedicated kernel).  Returns
     (a, saved) with saved = (x, y, scale, shift, mean, invstd) for block_bwd."""
     dev, cout = x.device, w.shape[0]
     if first:
         y, stats = first_fwd(x, w, bias, pad, training)
     else:
-        wpk = pack_weights(w, x.shape[3], x.dtype, dgrad=False)
+        if wpk is None:
+            wpk = pack_weights(w, x.shape[3], x.dtype, dgrad=False)
         y, stats = conv_fwd(x, wpk, bias, cout, pad, training, cin_real=w.shape[1])
-    scale = torch.empty(cout, device=dev, dtype=torch.float32)
-    shift, mean, invstd = torch.empty_like(scale), torch.empty_like(scale), torch.empty_like(scale)
+    scale, shift, mean, invstd = torch.empty(4, cout, device=dev, dtype=torch.float32).unbind(0)
     if training:
         count = float(y.shape[0] * y.shape[1] * y.shape[2])
         L.check(L.lib().vqa_bn_finalize(L.stream(), L.ptr(stats), stats.shape[0], cout, L.ctypes.c_double(count),
                                         L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv),
                                         L.ctypes.c_float(BN_MOMENTUM), L.ctypes.c_float(BN_EPS), L.ptr(mean),
-                                        L.ptr(invstd), L.ptr(scale), L.ptr(shift),
-                                        L.ptr(torch.empty(32 * cout * 2, device=dev, dtype=torch.float64))),
+                                        L.ptr(invstd), L.ptr(scale), L.ptr(shift)),
                 'vqa_bn_finalize')
     else:
         L.call('vqa_bn_eval_coeffs', cout, gamma, beta, rm, rv, BN_EPS, scale, shift)
@@ -197,7 +221,7 @@ def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False)
     return a, (x, y, scale, shift, mean, invstd)
 
 
-def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False):
+def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None):
     """d = gradient w.r.t. the block output (NHWC, activation dtype).  Returns (dx, dw, dbias, dgamma, dbeta)."""
     x, y, scale, shift, mean, invstd = saved
     dev = y.device
@@ -222,8 +246,9 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False):
     dbias = torch.zeros(C, device=dev, dtype=torch.float32)
     dx = None
     if need_dx:
-        wpk = pack_weights(w, x.shape[3], x.dtype, dgrad=True)
-        dx, _ = conv_fwd(dy, wpk, None, x.shape[3], 2 - pad, False, kind='dgrad')
+        if wpk_d is None:
+            wpk_d = pack_weights(w, x.shape[3], x.dtype, dgrad=True)
+        dx, _ = conv_fwd(dy, wpk_d, None, x.shape[3], 2 - pad, False, kind='dgrad')
     return dx, dw, dbias, dgamma, dbeta
 
 
@@ -237,12 +262,19 @@ class _CnnFunction(torch.autograd.Function):
         first = first_ok(images, params[0], dtype)
         x = images.contiguous() if first else to_nhwc(images, dtype)
         saved, meta = [], []
+        # every packed weight slab of the step (forward, and data-gradient when training) in one launch
+        cinp = [CIN0_PAD] + list(CHANNELS[1:10])
+        fjobs = [(params[4 * li], cinp[li], False) for li in range(10) if not (first and li == 0)]
+        djobs = [(params[4 * li], cinp[li], True) for li in range(1, 10)] if training else []
+        slabs = pack_all(fjobs + djobs, dtype)
+        wf = ([None] if first else []) + slabs[:len(fjobs)]
+        ctx.wd = [None] + slabs[len(fjobs):] if training else None
         for li in range(10):
             w, bias, gamma, beta = params[4 * li: 4 * li + 4]
             pad = padding if li in (0, 2, 4, 6) else 0
             pool = pool_mode if li % 2 == 1 else 0
             x, sv = block_fwd(x, w, bias, gamma, beta, buffers[2 * li], buffers[2 * li + 1], pad, pool, training,
-                              first=first and li == 0)
+                              first=first and li == 0, wpk=wf[li])
             saved += list(sv)
             meta.append((pad, pool))
         ctx.save_for_backward(*saved, *params)
@@ -263,7 +295,7 @@ class _CnnFunction(torch.autograd.Function):
         for li in range(9, -1, -1):
             pad, pool = ctx.meta[li]
             d, dw, db, dg, dbt = block_bwd(d, saved[6 * li: 6 * li + 6], params[4 * li], CHANNELS[li], pad, pool,
-                                           li > 0, first=ctx.first and li == 0)
+                                           li > 0, first=ctx.first and li == 0, wpk_d=ctx.wd[li])
             grads[4 * li: 4 * li + 4] = [dw, db, dg, dbt]
         return (None, None, *grads, *([None] * 20))
 

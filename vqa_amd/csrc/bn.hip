@@ -27,35 +27,27 @@ template <typename T> struct Vec {
     }
 };
 
-// Stage 1 of the statistics: grid (C, S) - slab s sums rows s, s+S, ... of the conv partials for one channel.
-__global__ void bn_stats_slab(const float* part, int rows, int C, double* slab /* [S][C][2] */) {
-    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+// One workgroup per channel: sums the conv epilogue's partial rows (a few hundred to a few thousand: one per
+// persistent conv workgroup) in fp64 in a fixed order, then produces the BN coefficients and running statistics.
+__global__ __launch_bounds__(256) void bn_finalize(const float* part, int rows, int C, double count,
+                                                   const float* gamma, const float* beta, float* running_mean,
+                                                   float* running_var, float momentum, float eps, float* mean,
+                                                   float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int i = s + threadIdx.x * S; i < rows; i += blockDim.x * S) {
-        s1 += (double)part[((long)i * C + c) * 2];
-        s2 += (double)part[((long)i * C + c) * 2 + 1];
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+        const float2 v = *reinterpret_cast<const float2*>(part + ((long)i * C + c) * 2);
+        s1 += (double)v.x;
+        s2 += (double)v.y;
     }
     __shared__ double r1[4], r2[4];
     s1 = wave_sum_d(s1);
     s2 = wave_sum_d(s2);
     if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        slab[((long)s * C + c) * 2] = r1[0] + r1[1] + r1[2] + r1[3];
-        slab[((long)s * C + c) * 2 + 1] = r2[0] + r2[1] + r2[2] + r2[3];
-    }
-}
-// Stage 2: one thread per channel combines the S slabs in fixed order and produces the BN coefficients.
-__global__ void bn_finalize(const double* slab, int S, int C, double count, const float* gamma, const float* beta,
-                            float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                            float* invstd, float* scale, float* shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int s = 0; s < S; ++s) {
-        s1 += slab[((long)s * C + c) * 2];
-        s2 += slab[((long)s * C + c) * 2 + 1];
-    }
+    if (threadIdx.x != 0) return;
+    s1 = r1[0] + r1[1] + r1[2] + r1[3];
+    s2 = r2[0] + r2[1] + r2[2] + r2[3];
     const double m = s1 / count;
     double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -272,15 +264,12 @@ int grid_for(long items, int per_block) {
 
 }  // namespace
 
-// slab: scratch of VQA_BN_SLABS * C * 2 doubles
 extern "C" int vqa_bn_finalize(void* stream, const float* part, int rows, int C, double count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                               float* mean, float* invstd, float* scale, float* shift, double* slab) {
-    constexpr int S = 32;   // VQA_BN_SLABS
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(bn_stats_slab, dim3(C, S), dim3(256), 0, st, part, rows, C, slab);
-    hipLaunchKernelGGL(bn_finalize, dim3((C + 63) / 64), dim3(64), 0, st, slab, S, C, count, gamma, beta, running_mean,
-                       running_var, momentum, eps, mean, invstd, scale, shift);
+                               float* mean, float* invstd, float* scale, float* shift) {
+    if (rows < 1 || C < 1) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize, dim3(C), dim3(256), 0, static_cast<hipStream_t>(stream), part, rows, C, count, gamma,
+                       beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
     CHECK_LAUNCH();
     return VQA_OK;
 }

@@ -739,6 +739,39 @@ __global__ void conv_pack(const float* w, T* out, int Cout, int Cin, int CinP, i
     out[i] = from_f32<T>(v);
 }
 
+// All conv layers' slabs (forward and data-gradient) in ONE launch: blockIdx.y = job.
+constexpr int PACK_MAX_JOBS = 24;
+struct PackJobs {
+    const float* w[PACK_MAX_JOBS];
+    void* out[PACK_MAX_JOBS];
+    int Cout[PACK_MAX_JOBS], Cin[PACK_MAX_JOBS], CinP[PACK_MAX_JOBS], CK[PACK_MAX_JOBS], KP[PACK_MAX_JOBS],
+        dgrad[PACK_MAX_JOBS];
+};
+template <typename T>
+__global__ void conv_pack_all(PackJobs j) {
+    const int b = blockIdx.y;
+    const float* w = j.w[b];
+    T* out = static_cast<T*>(j.out[b]);
+    const int Cout = j.Cout[b], Cin = j.Cin[b], CinP = j.CinP[b], CK = j.CK[b], KP = j.KP[b], dgrad = j.dgrad[b];
+    const int rows = dgrad ? CinP : Cout, red = dgrad ? Cout : CinP;
+    const long n = (long)(red / CK) * rows * KP;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int k = i % KP;
+        const int row = (i / KP) % rows;
+        const int ch = i / ((long)KP * rows);
+        float v = 0.f;
+        if (k < 9 * CK) {
+            const int tap = k / CK, c = ch * CK + k % CK;
+            if (!dgrad) {
+                if (c < Cin) v = w[((long)row * Cin + c) * 9 + tap];
+            } else {
+                if (row < Cin) v = w[((long)c * Cin + row) * 9 + (8 - tap)];
+            }
+        }
+        out[i] = from_f32<T>(v);
+    }
+}
+
 // images [B][C][H][W] (f32 / f16 / bf16) -> NHWC [B][H][W][CP] in T, channels >= C zero.  One thread per pixel:
 // coalesced plane reads (consecutive lanes = consecutive pixels), 16-byte stores of the CP-channel vector.
 template <typename TI, typename T>
@@ -857,6 +890,33 @@ extern "C" int vqa_conv_pack(void* stream, int dtype, const float* w, void* out,
         hipLaunchKernelGGL(conv_pack<float>, grid, dim3(256), 0, s, w, static_cast<float*>(out), Cout, Cin, CinP, CK, KP, dgrad);
     else
         return VQA_ERR_ARG;
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+// n jobs; w / out are HOST arrays of device pointers, desc is a host array of n x 6 ints
+// (Cout, Cin, CinP, CK, KP, dgrad): the arguments of n vqa_conv_pack calls, done by one launch.
+extern "C" int vqa_conv_pack_all(void* stream, int dtype, int n, const void* const* w, void* const* out,
+                                 const int* desc) {
+    if (n < 1 || n > PACK_MAX_JOBS || !w || !out || !desc) return VQA_ERR_ARG;
+    PackJobs j;
+    long nmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const int* d = desc + 6 * i;
+        const int rows = d[5] ? d[2] : d[0], red = d[5] ? d[0] : d[2];
+        if (d[3] < 1 || red % d[3]) return VQA_ERR_ARG;
+        j.w[i] = static_cast<const float*>(w[i]);
+        j.out[i] = out[i];
+        j.Cout[i] = d[0]; j.Cin[i] = d[1]; j.CinP[i] = d[2]; j.CK[i] = d[3]; j.KP[i] = d[4]; j.dgrad[i] = d[5];
+        const long ne = (long)(red / d[3]) * rows * d[4];
+        if (ne > nmax) nmax = ne;
+    }
+    long gb = (nmax + 255) / 256;
+    dim3 grid((unsigned)(gb > 256 ? 256 : gb), n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == VQA_BF16) hipLaunchKernelGGL(conv_pack_all<bf16>, grid, dim3(256), 0, s, j);
+    else if (dtype == VQA_F32) hipLaunchKernelGGL(conv_pack_all<float>, grid, dim3(256), 0, s, j);
+    else return VQA_ERR_ARG;
     CHECK_LAUNCH();
     return VQA_OK;
 }

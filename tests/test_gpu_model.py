@@ -114,3 +114,45 @@ def test_cpu_tensor_raises(tmp_path):
     m = build_model(c, tmp_path, 'fp32')
     with pytest.raises(VqaHipError):
         m(c['images'], c['questions'])
+
+
+def test_trainer_flat_gradients_and_step(tmp_path):
+    """optim.Trainer: the HIP backward writes every gradient straight into the flat buffer (autograd adopts the views:
+    no accumulation kernels, no copies), the result equals a plain loss.backward() on the same module, and the
+    clip + Adamax tail reproduces the reference's post-step parameters (golden psamp/*, total_norm)."""
+    import copy
+    import vqa_model
+    from oracle import vqa_oracle as O
+    from vqa_amd.optim import Trainer
+    c = load_case('h64_p5_max')
+    g = c['golden']
+    m = build_model(c, tmp_path, 'fp32').cuda().train()
+    m2 = copy.deepcopy(m)
+    img, q, t = c['images'].cuda(), c['questions'].cuda(), c['targets'].cuda()
+    vqa_model.SoftScoreBCELoss()(m2(img, q), t).backward()           # plain autograd: fresh gradient tensors
+    ref = {k: p.grad.clone() for k, p in m2.named_parameters()}
+    tr = Trainer(m, lr=2e-3, max_norm=0.25)
+    copies = []
+    orig = tr.flat.collect
+    def spy(params=None):
+        copies.extend(p for p in tr.flat.params if p.grad is None or p.grad.data_ptr() != p._vqa_grad_dst.data_ptr())
+        return orig(params)
+    tr.flat.collect = spy
+    tr.step(img, q, t, flip=False)
+    assert not copies, 'some gradients were not written in place'
+    names = dict(zip(tr.flat.names, tr.flat.params))
+    for k, r in ref.items():
+        got = names[k]._vqa_grad_dst.view(r.shape)
+        if k == 'gru.word_embedding.weight':                 # scatter-add by float atomics: order-dependent last bits
+            assert torch.allclose(got, r, rtol=1e-4, atol=1e-6), k
+        else:
+            assert torch.equal(got, r), k                    # same kernels, same bits
+    assert float(tr.opt.total_norm) == pytest.approx(float(g['total_norm']), rel=1e-3)
+    for k, p in m.named_parameters():
+        if k.startswith('cnn.convolutions') and k.endswith('.bias') and int(k.split('.')[2]) in O.CONV_IDX:
+            continue
+        d = np.abs(p.detach().reshape(-1).cpu().numpy()[sample_idx(p.numel())] - g[f'psamp/{k}'])
+        assert (d > 1e-4).mean() <= 0.07, k
+    # a second step: gradients are overwritten, not accumulated
+    tr.step(img, q, t, flip=False)
+    assert not copies

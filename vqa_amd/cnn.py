@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+from . import ops
 
 CHANNELS = [3, 16, 16, 32, 32, 64, 64, 128, 128, 256, 256]      # reference cnn.py:23-40
 CONV_IDX = [0, 3, 7, 10, 14, 17, 21, 24, 28, 31]
@@ -122,7 +123,7 @@ def _plan(*key):
     return _plans[key]
 
 
-def conv_wgrad(x, dy, cin_real, pad):
+def conv_wgrad(x, dy, cin_real, pad, out=None):
     B, IH, IW, cin = x.shape
     _, OH, OW, cout = dy.shape
     mt = 256 if x.dtype == torch.bfloat16 else 128
@@ -141,7 +142,7 @@ def conv_wgrad(x, dy, cin_real, pad):
     per_cu = max(1, min(waves, (160 * 1024) // lds))
     G = max(1, min(tiles, (256 * per_cu) // pairs if pairs <= 256 * per_cu else 1))
     part = torch.empty(G, cout, 9, cin, device=x.device, dtype=torch.float32)
-    dw = torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)
     tag = _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4)
     L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw, G, B, IH, IW, cin, cin_real, OH, OW, cout, pad, R, CW,
            tag=tag)
@@ -183,14 +184,14 @@ def first_fwd(images, w, bias, pad, want_stats):
     return y, stats
 
 
-def first_wgrad(images, dy, pad):
+def first_wgrad(images, dy, pad, out=None):
     B, _, IH, IW = images.shape
     _, OH, OW, _ = dy.shape
     R, CW = pick_tile(OH, OW)
     tiles = B * (-(-OH // R)) * (-(-OW // CW))
     G = min(tiles, 256 * 5)
     part = torch.empty(G, 16, 32, device=dy.device, dtype=torch.float32)
-    dw = torch.empty(16, 3, 3, 3, device=dy.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty(16, 3, 3, 3, device=dy.device, dtype=torch.float32)
     tag = dict(kind='first_wgrad', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
                bytes=float(images.numel() * images.element_size() + dy.numel() * 2))
     L.call('vqa_conv3x3_first_wgrad', L.dt(images), images, dy, part, dw, G, B, IH, IW, OH, OW, pad, R, CW, tag=tag)
@@ -221,7 +222,7 @@ def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False,
     return a, (x, y, scale, shift, mean, invstd)
 
 
-def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None):
+def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None, params=None):
     """d = gradient w.r.t. the block output (NHWC, activation dtype).  Returns (dx, dw, dbias, dgamma, dbeta)."""
     x, y, scale, shift, mean, invstd = saved
     dev = y.device
@@ -229,8 +230,15 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
     count = float(B * H * W)
     rows = L.lib().vqa_bn_bwd_rows(L.dt(y), B, H, W, C, pool)
     part = torch.empty(rows, C, 2, device=dev, dtype=torch.float32)
-    dgamma = torch.empty(C, device=dev, dtype=torch.float32)
-    dbeta, c1, c2 = torch.empty_like(dgamma), torch.empty_like(dgamma), torch.empty_like(dgamma)
+    # gradients go straight into the flat gradient buffer when the parameters live in one (ops.grad_dst)
+    _, pb, pg, pbt = params if params is not None else (None, None, None, None)
+    dw_out = ops.grad_dst(w)
+    dbias, dgamma, dbeta = (ops.grad_dst(t) if t is not None else None for t in (pb, pg, pbt))
+    if dgamma is None:
+        dgamma = torch.empty(C, device=dev, dtype=torch.float32)
+    if dbeta is None:
+        dbeta = torch.empty(C, device=dev, dtype=torch.float32)
+    c1, c2 = torch.empty(2, C, device=dev, dtype=torch.float32).unbind(0)
     dy = torch.empty_like(y)
     es = y.element_size()
     tag = dict(kind='reduce', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((y.numel() + d.numel()) * es))
@@ -240,10 +248,12 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
                                         L.ptr(dbeta), L.ptr(c1), L.ptr(c2)), 'vqa_bn_bwd_finalize')
     tag = dict(kind='apply', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((2 * y.numel() + d.numel()) * es))
     L.call('vqa_bn_bwd', L.dt(y), 1, y, d, dy, scale, shift, mean, invstd, c1, c2, None, B, H, W, C, pool, tag=tag)
-    dw = first_wgrad(x, dy, pad) if first else conv_wgrad(x, dy, cin_real, pad)
+    dw = first_wgrad(x, dy, pad, out=dw_out) if first else conv_wgrad(x, dy, cin_real, pad, out=dw_out)
     # the conv bias feeds a training-mode BatchNorm: its gradient is identically zero (the reference produces
     # rounding noise ~1e-7 of the weight-gradient scale here)
-    dbias = torch.zeros(C, device=dev, dtype=torch.float32)
+    # (its slot in the flat gradient buffer is never written: zero from FlatParams' initial fill)
+    if dbias is None:
+        dbias = torch.zeros(C, device=dev, dtype=torch.float32)
     dx = None
     if need_dx:
         if wpk_d is None:
@@ -295,7 +305,8 @@ class _CnnFunction(torch.autograd.Function):
         for li in range(9, -1, -1):
             pad, pool = ctx.meta[li]
             d, dw, db, dg, dbt = block_bwd(d, saved[6 * li: 6 * li + 6], params[4 * li], CHANNELS[li], pad, pool,
-                                           li > 0, first=ctx.first and li == 0, wpk_d=ctx.wd[li])
+                                           li > 0, first=ctx.first and li == 0, wpk_d=ctx.wd[li],
+                                           params=params[4 * li: 4 * li + 4])
             grads[4 * li: 4 * li + 4] = [dw, db, dg, dbt]
         return (None, None, *grads, *([None] * 20))
 

@@ -81,13 +81,13 @@ class _GruFunction(torch.autograd.Function):
                 ops.gemm(h_t[t], whh, out=gh, bias=b_hh)
                 L.call('vqa_gru_gate_fwd', L.dt(x), gi[t * B:(t + 1) * B], gh, h_f[t], B, H, h_f[t + 1], h_t[t + 1],
                        save[t])
-        ctx.save_for_backward(q, x, h_f, h_t, save, w_ih, w_hh, emb)
+        ctx.save_for_backward(q, x, h_f, h_t, save, w_ih, w_hh, emb, b_ih, b_hh)
         ctx.dtype = dtype
         return h_f[T].clone()
 
     @staticmethod
     def backward(ctx, dh_last):
-        q, x, h_f, h_t, save, w_ih, w_hh, emb = ctx.saved_tensors
+        q, x, h_f, h_t, save, w_ih, w_hh, emb, b_ih, b_hh = ctx.saved_tensors
         dtype = ctx.dtype
         B, T = q.shape
         E, H = emb.shape[1], w_hh.shape[1]
@@ -110,11 +110,13 @@ class _GruFunction(torch.autograd.Function):
                     ops.gemm(dgh[t * B:(t + 1) * B], whh_T, out=dprev, accumulate=True)   # += dgh_t @ W_hh
                 dh = dprev
         hprev = h_t[:T].reshape(T * B, H)
-        dw_hh = ops.gemm(dgh, hprev, trans=True)                 # [3H, H]
-        dw_ih = ops.gemm(dgi, x[:, :E], trans=True)              # [3H, E]
-        db_ih, db_hh = ops.colsum(dgi), ops.colsum(dgh)
+        # parameter gradients are written into the flat gradient buffer when there is one (ops.grad_dst)
+        dw_hh = ops.gemm(dgh, hprev, trans=True, out=ops.grad_dst(w_hh))          # [3H, H]
+        dw_ih = ops.gemm(dgi, x[:, :E], trans=True, out=ops.grad_dst(w_ih))       # [3H, E]
+        db_ih, db_hh = ops.colsum(dgi, out=ops.grad_dst(b_ih)), ops.colsum(dgh, out=ops.grad_dst(b_hh))
         dx = ops.gemm(dgi, wih_T)                                # [T*B, E] fp32
-        demb = torch.zeros_like(emb)
+        demb = ops.grad_dst(emb)
+        demb = torch.zeros_like(emb) if demb is None else demb.zero_()
         L.call('vqa_embed_bwd', q, dx, B, T, E, dx.stride(0), demb)
         return None, None, demb, dw_ih, dw_hh, db_ih, db_hh
 

@@ -55,6 +55,16 @@ def scratch(dev):
     return _scratch[key]
 
 
+def grad_dst(p):
+    """A fresh view of parameter p's slot in the flat gradient buffer (optim.FlatParams sets `_vqa_grad_dst`), or
+    None.  A backward that writes its result there and RETURNS this view lets autograd adopt it as p.grad without a
+    copy or an accumulation kernel; that is only valid while p.grad is None (nothing to accumulate into)."""
+    d = getattr(p, '_vqa_grad_dst', None)
+    if d is None or p.grad is not None:
+        return None
+    return d.view(p.shape)
+
+
 def dot(a, b):
     out = torch.empty(1, device=a.device, dtype=torch.float32)
     L.check(L.lib().vqa_dot(L.stream(), L.ptr(a), L.ptr(b), ctypes.c_long(a.numel()), L.ptr(scratch(a.device)),
@@ -62,10 +72,11 @@ def dot(a, b):
     return out
 
 
-def colsum(x, M=None, N=None):
+def colsum(x, M=None, N=None, out=None):
     M = x.shape[0] if M is None else M
     N = x.shape[1] if N is None else N
-    out = torch.empty(N, device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
     slabs = max(1, min(64, M // 64))
     scr = torch.empty(slabs, N, device=x.device, dtype=torch.float32) if slabs > 1 else None
     L.call('vqa_colsum', L.dt(x), x, M, N, x.stride(0), out, scr, slabs)
@@ -95,10 +106,13 @@ def weight_norm_fwd(v, g, dtype, transpose=True):
 
 
 def weight_norm_bwd(dw, v, g, sumsq):
-    """dW (fp32 [out,in] contiguous) -> (dg scalar, dv)."""
+    """dW (fp32 [out,in] contiguous) -> (dg scalar, dv); written into the flat gradient slots when there are any."""
     d = dot(dw, v)
-    dv = torch.empty_like(v)
-    dg = torch.empty((), device=v.device, dtype=torch.float32)
+    dv, dg = grad_dst(v), grad_dst(g)
+    if dv is None:
+        dv = torch.empty_like(v)
+    if dg is None:
+        dg = torch.empty((), device=v.device, dtype=torch.float32)
     L.check(L.lib().vqa_wn_bwd(L.stream(), L.ptr(dw), L.ptr(v), L.ptr(g), L.ptr(sumsq), L.ptr(d),
                                ctypes.c_long(v.numel()), L.ptr(dv), L.ptr(dg)), 'vqa_wn_bwd')
     return dg, dv

@@ -29,8 +29,10 @@ class FlatParams:
     def __init__(self, module):
         named = sorted(module.named_parameters(), key=lambda kv: _bucket_of(kv[0]))   # stable: head, gru, cnn
         dev = named[0][1].device
-        n = sum(p.numel() for _, p in named)
-        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        ALIGN = 64                                              # every parameter starts on a 256-byte boundary
+        pad = lambda k: -(-k // ALIGN) * ALIGN
+        n = sum(pad(p.numel()) for _, p in named)
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)     # the gaps stay zero in all four buffers
         self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
         self.names, self.params, self.bucket_ranges = [], [], []
         off, cur, start = 0, None, 0
@@ -43,18 +45,33 @@ class FlatParams:
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view(p.shape)
-            p.grad = self.grad[off:off + k].view(p.shape)
+            p.grad = None
+            # the HIP backward writes each gradient into its slot and hands autograd a view of it (ops.grad_dst): no
+            # accumulation kernels, no per-step memset of the flat buffer
+            p._vqa_grad_dst = self.grad[off:off + k]
             self.names.append(name)
             self.params.append(p)
-            off += k
+            off += pad(k)
         self.bucket_ranges.append((start, off))
         self.numel = n
 
     def zero_grad(self):
-        self.grad.zero_()
-        for p in self.params:           # keep .grad pointing into the flat buffer (autograd accumulates in place)
-            if p.grad is None or p.grad.data_ptr() < self.grad.data_ptr():
-                raise RuntimeError('parameter .grad was detached from the flat buffer (use zero_grad here)')
+        """Gradients are OVERWRITTEN by the next backward (slots never written - the conv biases under a training-mode
+        BatchNorm - stay at the initial zero), so "zeroing" is dropping the .grad references."""
+        for p in self.params:
+            p.grad = None
+
+    def collect(self, params=None):
+        """After backward: every p.grad must BE its slot of the flat buffer.  A gradient autograd produced elsewhere
+        (a second backward into existing grads, a foreign autograd path) is copied in, so the flat buffer is always
+        what the optimizer and the all-reduce see."""
+        for p in (self.params if params is None else params):
+            dst = p._vqa_grad_dst
+            if p.grad is None:
+                dst.zero_()
+            elif p.grad.data_ptr() != dst.data_ptr():
+                dst.copy_(p.grad.reshape(-1))
+                p.grad = dst.view(p.shape)
 
 
 class GradBuckets:
@@ -69,11 +86,10 @@ class GradBuckets:
         if self.world > 1:
             # a bucket is ready when the LAST of its parameters has accumulated its gradient
             ends = [e for _, e in flat.bucket_ranges]
-            off = 0
             self._bucket_idx = []
             for p in flat.params:
+                off = p._vqa_grad_dst.storage_offset()
                 self._bucket_idx.append(next(i for i, e in enumerate(ends) if off < e))
-                off += p.numel()
             for i, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(self._bucket_idx[i]))
         self.reset()
@@ -90,6 +106,7 @@ class GradBuckets:
         def hook(_p):
             self._left[b] -= 1
             if self._left[b] == 0:
+                self.flat.collect([q for q, bq in zip(self.flat.params, self._bucket_idx) if bq == b])
                 s, e = self.flat.bucket_ranges[b]
                 self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                                     async_op=True))
@@ -146,6 +163,8 @@ class Trainer:
         logits = self.model(images, questions)
         loss = self.criterion(logits, target)
         loss.backward()
+        if self.buckets.world == 1:
+            self.flat.collect()
         self.buckets.wait()
         self.opt.step()
         return loss.detach()

@@ -103,7 +103,8 @@ class _HeadFunction(torch.autograd.Function):
         logits = ops.gemm(m_t, W_fc)
         ctx.save_for_backward(v, q_t, v_t, a, w_s, p, vhat_t, fv, fq, m0, m, m_t, W_att_T, W_img_T, W_q_T, W_last_T,
                               W_fc_T, ss_att, ss_s, ss_img, ss_q, ss_last, ss_fc, g_att, v_att, g_s, v_s, g_img, v_img,
-                              g_q, v_q, g_last, v_last, g_fc, v_fc, *[t for t in masks if t is not None])
+                              g_q, v_q, g_last, v_last, g_fc, v_fc, b_att, b_img, b_q, b_last,
+                              *[t for t in masks if t is not None])
         ctx.dims, ctx.dtype, ctx.has_masks = (B, K, D, H, C), dtype, (mask1 is not None, mask2 is not None)
         return logits
 
@@ -111,8 +112,8 @@ class _HeadFunction(torch.autograd.Function):
     def backward(ctx, dlogits):
         (v, q_t, v_t, a, w_s, p, vhat_t, fv, fq, m0, m, m_t, W_att_T, W_img_T, W_q_T, W_last_T, W_fc_T, ss_att, ss_s,
          ss_img, ss_q, ss_last, ss_fc, g_att, v_att, g_s, v_s, g_img, v_img, g_q, v_q, g_last, v_last, g_fc,
-         v_fc) = ctx.saved_tensors[:35]
-        extra = list(ctx.saved_tensors[35:])
+         v_fc, b_att, b_img, b_q, b_last) = ctx.saved_tensors[:39]
+        extra = list(ctx.saved_tensors[39:])
         mask1 = extra.pop(0) if ctx.has_masks[0] else None
         mask2 = extra.pop(0) if ctx.has_masks[1] else None
         B, K, D, H, C = ctx.dims
@@ -125,15 +126,15 @@ class _HeadFunction(torch.autograd.Function):
         dpre_last = new(B, H)
         L.call('vqa_relu_bwd', L.dt(dpre_last), dm, m, mask2, B * H, dpre_last)
         dW_last = ops.gemm(dpre_last, m0, trans=True)
-        db_last = ops.colsum(dpre_last)
+        db_last = ops.colsum(dpre_last, out=ops.grad_dst(b_last))
         dm0 = ops.gemm(dpre_last, W_last_T)
         dpv, dpq = new(B, H), new(B, H)
         L.call('vqa_hadamard_bwd', L.dt(dpv), dm0, fv, fq, mask1, B * H, dpv, dpq)
         dW_img = ops.gemm(dpv, vhat_t, trans=True)                               # [H,D]
-        db_img = ops.colsum(dpv)
+        db_img = ops.colsum(dpv, out=ops.grad_dst(b_img))
         dvhat = ops.gemm(dpv, W_img_T)                                           # [B,D]
         dW_q = ops.gemm(dpq, q_t, trans=True)
-        db_q = ops.colsum(dpq)
+        db_q = ops.colsum(dpq, out=ops.grad_dst(b_q))
         dq = ops.gemm(dpq, W_q_T)                                                # [B,H]
         # attention
         dv = new(B * K, D, dt=torch.float32)
@@ -144,7 +145,7 @@ class _HeadFunction(torch.autograd.Function):
         ops.gemm(dpre_a, W_att_T[:D], out=dv, accumulate=True)                   # += dpre_a @ W_v
         dqa, dqa_t = new(B, H, dt=torch.float32), new(B, H)
         L.call('vqa_group_sum', L.dt(dpre_a), dpre_a, B, K, H, dqa, dqa_t)
-        db_att = ops.colsum(dqa)
+        db_att = ops.colsum(dqa, out=ops.grad_dst(b_att))
         dW_att = new(H, D + H, dt=torch.float32)
         ops.gemm(dpre_a, v_t, trans=True, out=dW_att[:, :D])
         ops.gemm(dqa_t, q_t, trans=True, out=dW_att[:, D:])

@@ -100,6 +100,14 @@ int vqa_wn_apply(void* stream, int dtype, const float* v, const float* g, const 
 /* weight_norm backward: dv = (g/n)(dW - (dot/n^2) v), dg = dot/n with n = sqrt(sumsq), dot = <dW, v>. */
 int vqa_wn_bwd(void* stream, const float* dw, const float* v, const float* g, const float* sumsq, const float* dot,
                long n, float* dv, float* dg);
+
+/* The same for all n (<= 8) weight-normed layers of the head in two launches per direction.  Pointer / int arguments
+ * are HOST arrays of length n holding device pointers; sumsq [n] f32 and part [n*64] f64 are device buffers.
+ * fwd dims = n x 4 ints (out, in, ldw, ldt), wt[i] may be NULL; bwd dims = n x 2 ints (out, in). */
+int vqa_wn_fwd_all(void* stream, int dtype, int n, const void* const* v, const void* const* g, void* const* w,
+                   void* const* wt, const int* dims, float* sumsq, double* part);
+int vqa_wn_bwd_all(void* stream, int n, const void* const* dw, const void* const* v, const void* const* g,
+                   void* const* dv, void* const* dg, const int* dims, const float* sumsq, double* part);
 /* dtype conversion with zero-padded leading dimension. */
 int vqa_cast_pad(void* stream, int src_dtype, int dst_dtype, const void* src, int M, int N, int lds, void* dst,
                  int ldd);

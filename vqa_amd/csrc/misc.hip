@@ -91,6 +91,110 @@ __global__ void wn_bwd(const float* dw, const float* v, const float* g, const fl
     if (blockIdx.x == 0 && threadIdx.x == 0) dg[0] = dot[0] / nrm;
 }
 
+// ---- all weight-normed layers of the head in two launches per direction (was 3 per layer per direction) --------
+// Launch 1 (wn_dots): grid (WN_SLABS, n): fixed-order fp64 partials of <v,v> (forward) or <dW,v> (backward).
+// Launch 2: forward wn_apply_all - every block re-sums its layer's WN_SLABS partials in one fixed order, then scales
+//           its 32x32 tile (and the transposed copy); backward wn_bwd_all - the same for dv / dg.
+constexpr int WN_MAX = 8, WN_SLABS = 64;
+struct WnJobs {
+    const float* v[WN_MAX];
+    const float* g[WN_MAX];
+    const float* dw[WN_MAX];      // backward: dW
+    void* w[WN_MAX];              // forward: W [out][ldw]
+    void* wt[WN_MAX];             // forward: W^T [in][ldt] or null
+    float* dv[WN_MAX];
+    float* dg[WN_MAX];
+    int out[WN_MAX], in[WN_MAX], ldw[WN_MAX], ldt[WN_MAX], tile0[WN_MAX + 1];
+    float* sumsq;                 // [n] forward: written; backward: read
+    double* part;                 // [n][WN_SLABS]
+    int n;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void wn_dots(WnJobs j) {
+    const int job = blockIdx.y;
+    const float* a = BWD ? j.dw[job] : j.v[job];
+    const float* b = j.v[job];
+    const long n = (long)j.out[job] * j.in[job];
+    double s = 0.0;
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+    if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) {
+        const long n4 = n >> 2;
+        for (long i = tid; i < n4; i += nth) {
+            const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+            s += (double)(x.x * y.x + x.y * y.y) + (double)(x.z * y.z + x.w * y.w);
+        }
+        for (long i = (n4 << 2) + tid; i < n; i += nth) s += (double)a[i] * (double)b[i];
+    } else {
+        for (long i = tid; i < n; i += nth) s += (double)a[i] * (double)b[i];
+    }
+    __shared__ double r[4];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) j.part[job * WN_SLABS + blockIdx.x] = r[0] + r[1] + r[2] + r[3];
+}
+
+// every thread of the block gets the layer's fixed-order sum of partials
+__device__ __forceinline__ float wn_total(const double* part, int job) {
+    __shared__ float tot;
+    if (threadIdx.x < 64) {
+        const double s = wave_sum_d(part[job * WN_SLABS + threadIdx.x]);
+        if (threadIdx.x == 0) tot = (float)s;
+    }
+    __syncthreads();
+    return tot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wn_apply_all(WnJobs j) {
+    int job = 0;
+    while (job + 1 < j.n && (int)blockIdx.x >= j.tile0[job + 1]) ++job;
+    const int tile = blockIdx.x - j.tile0[job];
+    const int out = j.out[job], in = j.in[job], ldw = j.ldw[job], ldt = j.ldt[job];
+    const int tiles_x = (in + 31) / 32;
+    const float sumsq = wn_total(j.part, job);
+    if (tile == 0 && threadIdx.x == 0) j.sumsq[job] = sumsq;
+    const float* v = j.v[job];
+    T* w = static_cast<T*>(j.w[job]);
+    T* wt = static_cast<T*>(j.wt[job]);
+    __shared__ float tl[32][33];
+    const float s = j.g[job][0] / sqrtf(sumsq);
+    const int o0 = (tile / tiles_x) * 32, i0 = (tile % tiles_x) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int o = o0 + r, i = i0 + tx;
+        float x = 0.f;
+        if (o < out && i < in) {
+            x = v[(long)o * in + i] * s;
+            w[(long)o * ldw + i] = from_f32<T>(x);
+        }
+        tl[r][tx] = x;
+    }
+    __syncthreads();
+    if (wt) {
+        for (int r = ty; r < 32; r += 8) {
+            const int i = i0 + r, o = o0 + tx;
+            if (i < in && o < out) wt[(long)i * ldt + o] = from_f32<T>(tl[tx][r]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wn_bwd_all(WnJobs j) {
+    const int job = blockIdx.y;
+    const float dot = wn_total(j.part, job);
+    const float sumsq = j.sumsq[job];
+    const float nrm = sqrtf(sumsq);
+    const float a = j.g[job][0] / nrm, b = dot / sumsq;
+    const long n = (long)j.out[job] * j.in[job];
+    const float* dw = j.dw[job];
+    const float* v = j.v[job];
+    float* dv = j.dv[job];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dv[i] = a * (dw[i] - b * v[i]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) j.dg[job][0] = dot / nrm;
+}
+
 // cast / pad: dst[m][0..ldd) = src[m][0..N) then zeros
 template <typename TS, typename TD>
 __global__ void cast_pad(const TS* src, int M, int N, int lds, TD* dst, int ldd) {
@@ -385,6 +489,47 @@ extern "C" int vqa_wn_apply(void* stream, int dtype, const float* v, const float
 extern "C" int vqa_wn_bwd(void* stream, const float* dw, const float* v, const float* g, const float* sumsq,
                           const float* dot, long n, float* dv, float* dg) {
     hipLaunchKernelGGL(wn_bwd, dim3(grid1d(n)), dim3(256), 0, ST, dw, v, g, sumsq, dot, n, dv, dg);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+// n (<= 8) weight-normed layers at once.  All pointer / int arguments are HOST arrays of length n (device pointers
+// inside); sumsq [n] f32 and part [n*64] f64 are device buffers.  dims = n x 4 ints (out, in, ldw, ldt).
+extern "C" int vqa_wn_fwd_all(void* stream, int dtype, int n, const void* const* v, const void* const* g,
+                              void* const* w, void* const* wt, const int* dims, float* sumsq, double* part) {
+    if (n < 1 || n > WN_MAX || !v || !g || !w || !wt || !dims || !sumsq || !part) return VQA_ERR_ARG;
+    WnJobs j{};
+    j.n = n; j.sumsq = sumsq; j.part = part;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        j.v[i] = static_cast<const float*>(v[i]); j.g[i] = static_cast<const float*>(g[i]);
+        j.w[i] = w[i]; j.wt[i] = wt[i];
+        j.out[i] = dims[4 * i]; j.in[i] = dims[4 * i + 1]; j.ldw[i] = dims[4 * i + 2]; j.ldt[i] = dims[4 * i + 3];
+        j.tile0[i] = tiles;
+        tiles += ((j.in[i] + 31) / 32) * ((j.out[i] + 31) / 32);
+    }
+    j.tile0[n] = tiles;
+    hipLaunchKernelGGL(wn_dots<false>, dim3(WN_SLABS, n), dim3(256), 0, ST, j);
+    BY_T(dtype, hipLaunchKernelGGL(wn_apply_all<bf16>, dim3(tiles), dim3(256), 0, ST, j),
+         hipLaunchKernelGGL(wn_apply_all<float>, dim3(tiles), dim3(256), 0, ST, j));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+// backward of the same: dv[i] (f32, shape of v) and dg[i] (scalar) from dW[i]; dims = n x 2 ints (out, in)
+extern "C" int vqa_wn_bwd_all(void* stream, int n, const void* const* dw, const void* const* v, const void* const* g,
+                              void* const* dv, void* const* dg, const int* dims, const float* sumsq, double* part) {
+    if (n < 1 || n > WN_MAX || !dw || !v || !g || !dv || !dg || !dims || !sumsq || !part) return VQA_ERR_ARG;
+    WnJobs j{};
+    j.n = n; j.sumsq = const_cast<float*>(sumsq); j.part = part;
+    for (int i = 0; i < n; ++i) {
+        j.dw[i] = static_cast<const float*>(dw[i]); j.v[i] = static_cast<const float*>(v[i]);
+        j.g[i] = static_cast<const float*>(g[i]);
+        j.dv[i] = static_cast<float*>(dv[i]); j.dg[i] = static_cast<float*>(dg[i]);
+        j.out[i] = dims[2 * i]; j.in[i] = dims[2 * i + 1];
+    }
+    hipLaunchKernelGGL(wn_dots<true>, dim3(WN_SLABS, n), dim3(256), 0, ST, j);
+    hipLaunchKernelGGL(wn_bwd_all, dim3(128, n), dim3(256), 0, ST, j);
     CHECK_LAUNCH();
     return VQA_OK;
 }

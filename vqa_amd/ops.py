@@ -118,6 +118,50 @@ def weight_norm_bwd(dw, v, g, sumsq):
     return dg, dv
 
 
+def _ptrs(ts):
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def weight_norm_fwd_all(layers, dtype):
+    """layers = [(v, g, transpose)]: weight_norm_fwd of all of them in two launches.
+    Returns ([(W, W^T or None)], sumsq [n] - kept for weight_norm_bwd_all)."""
+    n, dev = len(layers), layers[0][0].device
+    ws, wts, dims = [], [], []
+    for v, g, tr in layers:
+        out_f, in_f = v.shape
+        w = torch.empty(out_f, pad8(in_f), device=dev, dtype=dtype)
+        wt = torch.empty(in_f, pad8(out_f), device=dev, dtype=dtype) if tr else None
+        ws.append(w)
+        wts.append(wt)
+        dims += [out_f, in_f, w.stride(0), wt.stride(0) if tr else 0]
+    sumsq = torch.empty(n, device=dev, dtype=torch.float32)
+    part = torch.empty(n * 64, device=dev, dtype=torch.float64)
+    L.check(L.lib().vqa_wn_fwd_all(L.stream(), L.dt(ws[0]), n, _ptrs([l[0] for l in layers]),
+                                   _ptrs([l[1] for l in layers]), _ptrs(ws), _ptrs(wts),
+                                   (ctypes.c_int * (4 * n))(*dims), L.ptr(sumsq), L.ptr(part)), 'vqa_wn_fwd_all')
+    views = [(w[:, :l[0].shape[1]], None if wt is None else wt[:, :l[0].shape[0]])
+             for l, w, wt in zip(layers, ws, wts)]
+    return views, sumsq
+
+
+def weight_norm_bwd_all(items, sumsq):
+    """items = [(dW fp32 contiguous, v, g)] in the order of weight_norm_fwd_all -> [(dg, dv)], written into the flat
+    gradient slots when there are any."""
+    n, dev = len(items), items[0][1].device
+    dvs, dgs, dims = [], [], []
+    for dw, v, g in items:
+        assert dw.is_contiguous() and dw.dtype == torch.float32 and dw.numel() == v.numel()
+        dv, dg = grad_dst(v), grad_dst(g)
+        dvs.append(torch.empty_like(v) if dv is None else dv)
+        dgs.append(torch.empty((), device=dev, dtype=torch.float32) if dg is None else dg)
+        dims += [v.shape[0], v.shape[1]]
+    part = torch.empty(n * 64, device=dev, dtype=torch.float64)
+    L.check(L.lib().vqa_wn_bwd_all(L.stream(), n, _ptrs([i[0] for i in items]), _ptrs([i[1] for i in items]),
+                                   _ptrs([i[2] for i in items]), _ptrs(dvs), _ptrs(dgs),
+                                   (ctypes.c_int * (2 * n))(*dims), L.ptr(sumsq), L.ptr(part)), 'vqa_wn_bwd_all')
+    return list(zip(dgs, dvs))
+
+
 def bce_sum(logits, target, want_grad=True):
     """sum-reduced BCE-with-logits (reference vqa_model.py:215) -> (loss [1], dlogits or None)."""
     B, C = logits.shape

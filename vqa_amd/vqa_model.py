@@ -78,12 +78,10 @@ class _HeadFunction(torch.autograd.Function):
         v = v.contiguous()
         q = q.contiguous()
         mask1, mask2 = masks
-        W_att, W_att_T, ss_att = ops.weight_norm_fwd(v_att, g_att, dtype)      # [H, D+H]
-        w_s, _, ss_s = ops.weight_norm_fwd(v_s, g_s, dtype, transpose=False)   # [1, H]
-        W_img, W_img_T, ss_img = ops.weight_norm_fwd(v_img, g_img, dtype)
-        W_q, W_q_T, ss_q = ops.weight_norm_fwd(v_q, g_q, dtype)
-        W_last, W_last_T, ss_last = ops.weight_norm_fwd(v_last, g_last, dtype)
-        W_fc, W_fc_T, ss_fc = ops.weight_norm_fwd(v_fc, g_fc, dtype)
+        # all six weight-normed layers: W = g * v / ||v||_F (and W^T for the backward) in two launches
+        wn, ss = ops.weight_norm_fwd_all([(v_att, g_att, True), (v_s, g_s, False), (v_img, g_img, True),
+                                          (v_q, g_q, True), (v_last, g_last, True), (v_fc, g_fc, True)], dtype)
+        (W_att, W_att_T), (w_s, _), (W_img, W_img_T), (W_q, W_q_T), (W_last, W_last_T), (W_fc, W_fc_T) = wn
 
         v_t = ops.cast_pad(v.reshape(B * K, D), dtype)
         q_t = ops.cast_pad(q, dtype)
@@ -102,7 +100,7 @@ class _HeadFunction(torch.autograd.Function):
         L.call('vqa_mask_mul', L.dt(m_t), m, mask2, B * H, m_t)
         logits = ops.gemm(m_t, W_fc)
         ctx.save_for_backward(v, q_t, v_t, a, w_s, p, vhat_t, fv, fq, m0, m, m_t, W_att_T, W_img_T, W_q_T, W_last_T,
-                              W_fc_T, ss_att, ss_s, ss_img, ss_q, ss_last, ss_fc, g_att, v_att, g_s, v_s, g_img, v_img,
+                              W_fc_T, ss, g_att, v_att, g_s, v_s, g_img, v_img,
                               g_q, v_q, g_last, v_last, g_fc, v_fc, b_att, b_img, b_q, b_last,
                               *[t for t in masks if t is not None])
         ctx.dims, ctx.dtype, ctx.has_masks = (B, K, D, H, C), dtype, (mask1 is not None, mask2 is not None)
@@ -110,10 +108,10 @@ class _HeadFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits):
-        (v, q_t, v_t, a, w_s, p, vhat_t, fv, fq, m0, m, m_t, W_att_T, W_img_T, W_q_T, W_last_T, W_fc_T, ss_att, ss_s,
-         ss_img, ss_q, ss_last, ss_fc, g_att, v_att, g_s, v_s, g_img, v_img, g_q, v_q, g_last, v_last, g_fc,
-         v_fc, b_att, b_img, b_q, b_last) = ctx.saved_tensors[:39]
-        extra = list(ctx.saved_tensors[39:])
+        (v, q_t, v_t, a, w_s, p, vhat_t, fv, fq, m0, m, m_t, W_att_T, W_img_T, W_q_T, W_last_T, W_fc_T, ss,
+         g_att, v_att, g_s, v_s, g_img, v_img, g_q, v_q, g_last, v_last, g_fc,
+         v_fc, b_att, b_img, b_q, b_last) = ctx.saved_tensors[:34]
+        extra = list(ctx.saved_tensors[34:])
         mask1 = extra.pop(0) if ctx.has_masks[0] else None
         mask2 = extra.pop(0) if ctx.has_masks[1] else None
         B, K, D, H, C = ctx.dims
@@ -151,12 +149,10 @@ class _HeadFunction(torch.autograd.Function):
         ops.gemm(dqa_t, q_t, trans=True, out=dW_att[:, D:])
         ops.gemm(dqa_t, W_att_T[D:], out=dq, accumulate=True)                    # += dqa @ W_q-part
         # weight-norm backward
-        dg_att, dv_att = ops.weight_norm_bwd(dW_att, v_att, g_att, ss_att)
-        dg_s, dv_s = ops.weight_norm_bwd(dW_s, v_s, g_s, ss_s)
-        dg_img, dv_img = ops.weight_norm_bwd(dW_img, v_img, g_img, ss_img)
-        dg_q, dv_q = ops.weight_norm_bwd(dW_q, v_q, g_q, ss_q)
-        dg_last, dv_last = ops.weight_norm_bwd(dW_last, v_last, g_last, ss_last)
-        dg_fc, dv_fc = ops.weight_norm_bwd(dW_fc, v_fc, g_fc, ss_fc)
+        ((dg_att, dv_att), (dg_s, dv_s), (dg_img, dv_img), (dg_q, dv_q), (dg_last, dv_last),
+         (dg_fc, dv_fc)) = ops.weight_norm_bwd_all([(dW_att, v_att, g_att), (dW_s, v_s, g_s), (dW_img, v_img, g_img),
+                                                    (dW_q, v_q, g_q), (dW_last, v_last, g_last), (dW_fc, v_fc, g_fc)],
+                                                   ss)
         return (dv.reshape(B, K, D), dq, None, None, dg_att, dv_att, db_att, dg_s, dv_s, dg_img, dv_img, db_img, dg_q,
                 dv_q, db_q, dg_last, dv_last, db_last, dg_fc, dv_fc)
 

@@ -80,6 +80,19 @@ def cpu_baseline(hidden, classes, vocab, seconds=20.0):
                       f'{len(times)} steps after 2 warm-up'}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (scripts/pmc_traffic.sh: separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this bench; counters are in KB).  gfx950 correction of
+    MI355X_MICROARCH.md (HBM): FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane reads at 64 bytes, so it is
+    doubled; WRITE_SIZE is exact for 16/8-byte streaming stores.  None when no profile is committed for the kernel."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    try:
+        rec = json.load(open(path))[kernel]
+        return round((2.0 * rec['FETCH_SIZE'] + rec['WRITE_SIZE']) * 1024.0 / rec['launches'])
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
 # C-ABI entry point -> the device kernel (template family) that does its work
 KERNEL_OF = {'vqa_conv3x3_fwd': 'conv3x3_igemm', 'vqa_conv3x3_wgrad': 'conv3x3_wgrad', 'vqa_gemm': 'gemm_bf16',
              'vqa_bn_bwd': 'bn_bwd', 'vqa_bn_act_pool_fwd': 'bn_act_pool_fwd'}
@@ -120,6 +133,7 @@ def roofline_leg(trainer, batch):
     out = {'kernel': dom, 'bound': bound, 'launches_per_step': r['n'], 'avg_launch_ms': round(r['ms'] / r['n'], 4),
            'traffic': None, 'tflops': round(tfl, 2), 'gbs': round(gbs, 1),
            'algorithmic_bytes_per_launch': round(r['bytes'] / r['n']), 'kernel_ms_per_step': round(r['ms'], 3)}
+    out['traffic'] = pmc_traffic(dom)
     if bound == 'hbm':
         out.update(achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
     else:

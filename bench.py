@@ -156,6 +156,9 @@ def main():
     ap.add_argument('--hidden', type=int, default=1024)
     ap.add_argument('--image', type=int, default=224)
     ap.add_argument('--tokens', type=int, default=14)
+    ap.add_argument('--mode', default='train', choices=['train', 'eval'],
+                    help="'eval' = BASELINE.json configs[3]: forward + argmax + soft accuracy, eval-mode BatchNorm "
+                         "(use --batch 1024); the headline / driver contract is the default 'train'")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='also print the per-kernel time table to stderr')
     args = ap.parse_args()
@@ -197,12 +200,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.mode == 'eval':
+        from vqa_amd import ops
+        model.eval()
+
+        def step(images, questions, target):
+            with torch.no_grad():
+                return ops.soft_accuracy_sum(model(images, questions), target)   # device scalar, no host sync
+    else:
+        step = trainer.step
     for _ in range(args.warmup):
-        loss = trainer.step(*batch)
+        loss = step(*batch)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.step(*batch)
+        loss = step(*batch)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -213,11 +225,26 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
+    if args.mode == 'eval':
+        if world > 1:
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({'metric': 'eval samples/sec (node)', 'value': round(value, 1), 'unit': 'samples/s',
+                              'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                              'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
+                              'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+                              'config': {'workload': 'BASELINE.json configs[3]: eval forward + argmax + soft accuracy, '
+                                                     f'{args.precision}, batch {B}/GPU, {args.image}x{args.image}, '
+                                                     f'{args.tokens} tokens, H={args.hidden}',
+                                         'soft_accuracy_sum': round(final_loss, 3)}}), flush=True)
+        return
     result = {
         'metric': 'train samples/sec (node)', 'value': round(value, 1), 'unit': 'samples/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
-        'config': {'workload': 'BASELINE.json configs[1]: VQA training step (fwd+bwd+clip+Adamax), '
+        'config': {'workload': ('BASELINE.json configs[1]' if (args.image, args.tokens, args.hidden, B) == (224, 14, 1024, 256)
+                                else 'BASELINE.json configs[4]' if (args.image, args.tokens, args.hidden) == (448, 30, 2048)
+                                else 'non-headline variant') + ': VQA training step (fwd+bwd+clip+Adamax), '
                                f'{args.precision}, batch {B}/GPU, {args.image}x{args.image} images, {args.tokens} tokens, '
                                f'{classes} answers, H={args.hidden}, V={vocab}, padding 2, max-pool, dropout 0',
                    'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}',

@@ -160,6 +160,14 @@ int vqa_bce_sum(void* stream, const float* logits, const float* target, int B, i
 /* vqa_model.py:127-130 without the per-sample host loop: acc[0] = sum_b target[b][argmax_c logits[b][c]]. */
 int vqa_soft_accuracy_sum(void* stream, const float* logits, const float* target, int B, int C, int ldx, float* rows,
                           float* acc);
+
+/* The same two from SPARSE soft-score targets: the (labels, scores) lists that dataset.py:135-138
+ * scatters into the dense [B][C] matrix.  labels int64 [B][L] (< 0 = empty slot, distinct within a row), scores f32
+ * [B][L], L <= 256.  rowloss: B doubles of scratch; rows: B floats of scratch. */
+int vqa_bce_sum_sparse(void* stream, const float* logits, const long* labels, const float* scores, int B, int C, int L,
+                       int ldx, float* dlogits, double* rowloss, float* loss);
+int vqa_soft_accuracy_sum_sparse(void* stream, const float* logits, const long* labels, const float* scores, int B,
+                                 int C, int L, int ldx, float* rows, float* acc);
 /* nn.utils.clip_grad_norm_(max_norm, 2) + optim.Adamax step (vqa_model.py:259, :218, :266) over one flat f32
  * parameter / gradient buffer, no host synchronisation; max_norm <= 0 skips the clip. */
 int vqa_clip_adamax(void* stream, float* p, const float* g, float* m, float* u, long n, float max_norm, float lr,

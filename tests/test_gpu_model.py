@@ -156,3 +156,35 @@ def test_trainer_flat_gradients_and_step(tmp_path):
     # a second step: gradients are overwritten, not accumulated
     tr.step(img, q, t, flip=False)
     assert not copies
+
+
+def test_sparse_targets_match_dense(tmp_path):
+    """Sparse (labels, scores) targets: loss, dlogits and soft accuracy equal the dense [B,C] path
+    and the oracle's BCE on the densified matrix."""
+    import vqa_model
+    from oracle import vqa_oracle as O
+    from vqa_amd import ops, synth
+    B, C, L = 37, 3129, 10
+    torch.manual_seed(3)
+    logits = (torch.randn(B, C) * 3).cuda().requires_grad_(True)
+    dense = synth.targets(77, B, C)
+    labels = torch.full((B, L), -1, dtype=torch.int64)
+    scores = torch.zeros(B, L)
+    for b in range(B):
+        nz = dense[b].nonzero().flatten()
+        labels[b, :len(nz)] = nz
+        scores[b, :len(nz)] = dense[b, nz]
+    with torch.no_grad():                                  # make every row's arg-max a scored label now and then
+        for b in range(0, B, 3):
+            logits[b, labels[b, 0]] = 50.0
+    crit = vqa_model.SoftScoreBCELoss()
+    ld = crit(logits, dense.cuda())
+    gd, = torch.autograd.grad(ld, logits)
+    ls = crit(logits, (labels.cuda(), scores.cuda()))
+    gs, = torch.autograd.grad(ls, logits)
+    assert float(ls.detach()) == pytest.approx(float(ld.detach()), rel=1e-6)
+    assert torch.allclose(gs, gd, atol=1e-7)
+    assert float(ls.detach()) == pytest.approx(float(O.bce_sum(logits.detach().cpu(), dense)), rel=1e-5)
+    a_d = float(ops.soft_accuracy_sum(logits.detach(), dense.cuda()))
+    a_s = float(ops.soft_accuracy_sum(logits.detach(), (labels.cuda(), scores.cuda())))
+    assert a_s == pytest.approx(a_d, abs=1e-6) and a_d > 0

@@ -413,6 +413,55 @@ __global__ void soft_acc_rows(const float* x, const float* t, int C, int ldx, fl
     }
     if (lane == 0) out[b] = t[(long)b * C + bi];
 }
+// Sparse soft-score targets: row b has L slots (label, score), label < 0 = empty slot, labels distinct within a row -
+// the (labels, scores) lists the reference densifies into a >= 99.6 %-zero [B][C] matrix (dataset.py:135-138).
+// One workgroup per row: dense pass for the target-free terms, then the L slots.
+__global__ __launch_bounds__(256) void bce_sparse_rows(const float* x, const long* labels, const float* scores, int C,
+                                                       int L, int ldx, float* dx, double* rowloss) {
+    const int b = blockIdx.x;
+    const float* xr = x + (long)b * ldx;
+    double s = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float xv = xr[c];
+        const float e = __expf(-fabsf(xv));
+        s += (double)(fmaxf(xv, 0.f) + log1pf(e));
+        if (dx) dx[(long)b * C + c] = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    }
+    __syncthreads();                                   // this block's dx row is written (same-block visibility)
+    if ((int)threadIdx.x < L) {
+        const long lb = labels[(long)b * L + threadIdx.x];
+        if (lb >= 0 && lb < C) {
+            const float sc = scores[(long)b * L + threadIdx.x];
+            s -= (double)(xr[lb] * sc);
+            if (dx) dx[(long)b * C + lb] -= sc;
+        }
+    }
+    __shared__ double r[4];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) rowloss[b] = r[0] + r[1] + r[2] + r[3];
+}
+__global__ void soft_acc_rows_sparse(const float* x, const long* labels, const float* scores, int C, int L, int ldx,
+                                     float* out) {
+    const int b = blockIdx.x, lane = threadIdx.x;   // one wave per row
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = x[(long)b * ldx + c];
+        if (v > best) { best = v; bi = c; }
+    }
+    for (int o = 1; o < 64; o <<= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    float sc = 0.f;
+    for (int l = lane; l < L; l += 64)
+        if (labels[(long)b * L + l] == bi) sc = scores[(long)b * L + l];
+    sc = wave_sum(sc);                                // at most one slot matches (labels are distinct)
+    if (lane == 0) out[b] = sc;
+}
 __global__ void sum_f32(const float* x, int n, float* out) {
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 64) s += (double)x[i];
@@ -655,6 +704,25 @@ extern "C" int vqa_bce_sum(void* stream, const float* logits, const float* targe
 extern "C" int vqa_soft_accuracy_sum(void* stream, const float* logits, const float* target, int B, int C, int ldx,
                                      float* rows, float* acc) {
     hipLaunchKernelGGL(soft_acc_rows, dim3(B), dim3(64), 0, ST, logits, target, C, ldx, rows);
+    hipLaunchKernelGGL(sum_f32, dim3(1), dim3(64), 0, ST, rows, B, acc);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+// The same loss / accuracy from sparse targets: labels int64 [B][L] (< 0 = empty), scores f32 [B][L], L <= 256.
+// rowloss: B doubles of scratch; rows: B floats of scratch.
+extern "C" int vqa_bce_sum_sparse(void* stream, const float* logits, const long* labels, const float* scores, int B,
+                                  int C, int L, int ldx, float* dlogits, double* rowloss, float* loss) {
+    if (B < 1 || C < 1 || L < 1 || L > 256) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(bce_sparse_rows, dim3(B), dim3(256), 0, ST, logits, labels, scores, C, L, ldx, dlogits, rowloss);
+    hipLaunchKernelGGL(dot_final, dim3(1), dim3(64), 0, ST, rowloss, B, loss);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+extern "C" int vqa_soft_accuracy_sum_sparse(void* stream, const float* logits, const long* labels, const float* scores,
+                                            int B, int C, int L, int ldx, float* rows, float* acc) {
+    if (B < 1 || C < 1 || L < 1) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(soft_acc_rows_sparse, dim3(B), dim3(64), 0, ST, logits, labels, scores, C, L, ldx, rows);
     hipLaunchKernelGGL(sum_f32, dim3(1), dim3(64), 0, ST, rows, B, acc);
     CHECK_LAUNCH();
     return VQA_OK;

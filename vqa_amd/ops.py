@@ -171,10 +171,34 @@ def bce_sum(logits, target, want_grad=True):
     return loss, dl
 
 
+def _sparse(target):
+    """(labels int64 [B,L], scores fp32 [B,L]) if `target` is the sparse form, else None."""
+    if isinstance(target, (tuple, list)) and len(target) == 2:
+        labels, scores = target
+        assert labels.dtype == torch.int64 and labels.shape == scores.shape and labels.dim() == 2
+        return labels.contiguous(), scores.float().contiguous()
+    return None
+
+
+def bce_sum_sparse(logits, labels, scores, want_grad=True):
+    """bce_sum with sparse soft-score targets: row b has the (label, score) slots labels[b], scores[b]; label < 0 is
+    an empty slot; labels are distinct within a row (compute_softscore.py:192-239 produces them so)."""
+    B, C = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    dl = torch.empty(B, C, device=logits.device, dtype=torch.float32) if want_grad else None
+    rowloss = torch.empty(B, device=logits.device, dtype=torch.float64)
+    L.call('vqa_bce_sum_sparse', logits, labels, scores, B, C, labels.shape[1], logits.stride(0), dl, rowloss, loss)
+    return loss, dl
+
+
 def soft_accuracy_sum(logits, target):
     """sum_b target[b, argmax logits[b]] on the device (reference vqa_model.py:127-130) -> tensor [1]."""
     B, C = logits.shape
     rows = torch.empty(B, device=logits.device, dtype=torch.float32)
     acc = torch.empty(1, device=logits.device, dtype=torch.float32)
+    sp = _sparse(target)
+    if sp is not None:
+        L.call('vqa_soft_accuracy_sum_sparse', logits, sp[0], sp[1], B, C, sp[0].shape[1], logits.stride(0), rows, acc)
+        return acc
     L.call('vqa_soft_accuracy_sum', logits, target.contiguous(), B, C, logits.stride(0), rows, acc)
     return acc

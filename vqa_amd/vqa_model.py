@@ -236,23 +236,31 @@ VQAModel = VQA   # the name BASELINE.json's north_star uses
 
 class _BceSum(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target):
-        loss, dl = ops.bce_sum(logits, target.contiguous(), want_grad=True)
+    def forward(ctx, logits, target, scores):
+        if scores is None:
+            loss, dl = ops.bce_sum(logits, target.contiguous(), want_grad=True)
+        else:                                           # sparse form: target = labels int64 [B,L], scores [B,L]
+            loss, dl = ops.bce_sum_sparse(logits, target, scores, want_grad=True)
         ctx.save_for_backward(dl)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, go):
         (dl,) = ctx.saved_tensors
-        return dl * go, None
+        return dl * go, None, None
 
 
 class SoftScoreBCELoss(nn.Module):
     """nn.BCEWithLogitsLoss(reduction='sum') against dense soft-score targets (vqa_model.py:215) as one fused HIP
-    kernel producing the loss and sigmoid(x) - t in a single pass over the logits."""
+    kernel producing the loss and sigmoid(x) - t in a single pass over the logits.  `target` is the reference's
+    dense fp32 [B,C] matrix, or - SURVEY.md 8f-3 - the sparse pair (labels int64 [B,L] with -1 for empty slots,
+    scores fp32 [B,L]) that dataset.py:135-138 would scatter into it."""
 
     def forward(self, logits, target):
-        return _BceSum.apply(logits, target)
+        sp = ops._sparse(target)
+        if sp is not None:
+            return _BceSum.apply(logits, sp[0], sp[1])
+        return _BceSum.apply(logits, target, None)
 
 
 def evaluate(dataloader, model, criterion, last_epoch_acc, dataset):

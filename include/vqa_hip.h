@@ -102,7 +102,7 @@ int vqa_wn_bwd(void* stream, const float* dw, const float* v, const float* g, co
                long n, float* dv, float* dg);
 
 /* The same for all n (<= 8) weight-normed layers of the head in two launches per direction.  Pointer / int arguments
- * are HOST arrays of length n holding device pointers; sumsq [n] f32 and part [n*64] f64 are device buffers.
+ * are HOST arrays of length n holding device pointers; sumsq [n] f32 and part [n*256] f64 are device buffers.
  * fwd dims = n x 4 ints (out, in, ldw, ldt), wt[i] may be NULL; bwd dims = n x 2 ints (out, in). */
 int vqa_wn_fwd_all(void* stream, int dtype, int n, const void* const* v, const void* const* g, void* const* w,
                    void* const* wt, const int* dims, float* sumsq, double* part);
@@ -169,7 +169,7 @@ int vqa_bce_sum_sparse(void* stream, const float* logits, const long* labels, co
 int vqa_soft_accuracy_sum_sparse(void* stream, const float* logits, const long* labels, const float* scores, int B,
                                  int C, int L, int ldx, float* rows, float* acc);
 /* nn.utils.clip_grad_norm_(max_norm, 2) + optim.Adamax step (vqa_model.py:259, :218, :266) over one flat f32
- * parameter / gradient buffer, no host synchronisation; max_norm <= 0 skips the clip. */
+ * parameter / gradient buffer, no host synchronisation; max_norm <= 0 skips the clip.  part = 1024 doubles of scratch. */
 int vqa_clip_adamax(void* stream, float* p, const float* g, float* m, float* u, long n, float max_norm, float lr,
                     float b1, float b2, float eps, int step, double* part, float* sq, float* coef,
                     float* total_norm);

@@ -95,7 +95,7 @@ __global__ void wn_bwd(const float* dw, const float* v, const float* g, const fl
 // Launch 1 (wn_dots): grid (WN_SLABS, n): fixed-order fp64 partials of <v,v> (forward) or <dW,v> (backward).
 // Launch 2: forward wn_apply_all - every block re-sums its layer's WN_SLABS partials in one fixed order, then scales
 //           its 32x32 tile (and the transposed copy); backward wn_bwd_all - the same for dv / dg.
-constexpr int WN_MAX = 8, WN_SLABS = 64;
+constexpr int WN_MAX = 8, WN_SLABS = 256;
 struct WnJobs {
     const float* v[WN_MAX];
     const float* g[WN_MAX];
@@ -139,7 +139,10 @@ __global__ __launch_bounds__(256) void wn_dots(WnJobs j) {
 __device__ __forceinline__ float wn_total(const double* part, int job) {
     __shared__ float tot;
     if (threadIdx.x < 64) {
-        const double s = wave_sum_d(part[job * WN_SLABS + threadIdx.x]);
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < WN_SLABS / 64; ++i) s += part[job * WN_SLABS + i * 64 + threadIdx.x];
+        s = wave_sum_d(s);
         if (threadIdx.x == 0) tot = (float)s;
     }
     __syncthreads();
@@ -543,7 +546,7 @@ extern "C" int vqa_wn_bwd(void* stream, const float* dw, const float* v, const f
 }
 
 // n (<= 8) weight-normed layers at once.  All pointer / int arguments are HOST arrays of length n (device pointers
-// inside); sumsq [n] f32 and part [n*64] f64 are device buffers.  dims = n x 4 ints (out, in, ldw, ldt).
+// inside); sumsq [n] f32 and part [n*256] f64 are device buffers.  dims = n x 4 ints (out, in, ldw, ldt).
 extern "C" int vqa_wn_fwd_all(void* stream, int dtype, int n, const void* const* v, const void* const* g,
                               void* const* w, void* const* wt, const int* dims, float* sumsq, double* part) {
     if (n < 1 || n > WN_MAX || !v || !g || !w || !wt || !dims || !sumsq || !part) return VQA_ERR_ARG;
@@ -578,7 +581,7 @@ extern "C" int vqa_wn_bwd_all(void* stream, int n, const void* const* dw, const 
         j.out[i] = dims[2 * i]; j.in[i] = dims[2 * i + 1];
     }
     hipLaunchKernelGGL(wn_dots<true>, dim3(WN_SLABS, n), dim3(256), 0, ST, j);
-    hipLaunchKernelGGL(wn_bwd_all, dim3(128, n), dim3(256), 0, ST, j);
+    hipLaunchKernelGGL(wn_bwd_all, dim3(512, n), dim3(256), 0, ST, j);
     CHECK_LAUNCH();
     return VQA_OK;
 }
@@ -729,15 +732,15 @@ extern "C" int vqa_soft_accuracy_sum_sparse(void* stream, const float* logits, c
 }
 
 // Global-norm clip + Adamax over ONE flat fp32 parameter / gradient buffer, no host synchronisation.
-// state: m, u (n floats each); scratch: part (256 doubles), sq/coef/total_norm (1 float each).
+// state: m, u (n floats each); scratch: part (1024 doubles), sq/coef/total_norm (1 float each).
 extern "C" int vqa_clip_adamax(void* stream, float* p, const float* g, float* m, float* u, long n, float max_norm,
                                float lr, float b1, float b2, float eps, int step, double* part, float* sq,
                                float* coef, float* total_norm) {
     if (n <= 0 || step < 1) return VQA_ERR_ARG;
     const float* cp = nullptr;
     if (max_norm > 0.f) {
-        hipLaunchKernelGGL(dot_partial, dim3(256), dim3(256), 0, ST, g, g, n, part);
-        hipLaunchKernelGGL(dot_final, dim3(1), dim3(64), 0, ST, part, 256, sq);
+        hipLaunchKernelGGL(dot_partial, dim3(1024), dim3(256), 0, ST, g, g, n, part);
+        hipLaunchKernelGGL(dot_final, dim3(1), dim3(64), 0, ST, part, 1024, sq);
         hipLaunchKernelGGL(clip_coef, dim3(1), dim3(1), 0, ST, sq, max_norm, coef, total_norm);
         cp = coef;
     }

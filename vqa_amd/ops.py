@@ -135,7 +135,7 @@ def weight_norm_fwd_all(layers, dtype):
         wts.append(wt)
         dims += [out_f, in_f, w.stride(0), wt.stride(0) if tr else 0]
     sumsq = torch.empty(n, device=dev, dtype=torch.float32)
-    part = torch.empty(n * 64, device=dev, dtype=torch.float64)
+    part = torch.empty(n * 256, device=dev, dtype=torch.float64)
     L.check(L.lib().vqa_wn_fwd_all(L.stream(), L.dt(ws[0]), n, _ptrs([l[0] for l in layers]),
                                    _ptrs([l[1] for l in layers]), _ptrs(ws), _ptrs(wts),
                                    (ctypes.c_int * (4 * n))(*dims), L.ptr(sumsq), L.ptr(part)), 'vqa_wn_fwd_all')
@@ -155,7 +155,7 @@ def weight_norm_bwd_all(items, sumsq):
         dvs.append(torch.empty_like(v) if dv is None else dv)
         dgs.append(torch.empty((), device=dev, dtype=torch.float32) if dg is None else dg)
         dims += [v.shape[0], v.shape[1]]
-    part = torch.empty(n * 64, device=dev, dtype=torch.float64)
+    part = torch.empty(n * 256, device=dev, dtype=torch.float64)
     L.check(L.lib().vqa_wn_bwd_all(L.stream(), n, _ptrs([i[0] for i in items]), _ptrs([i[1] for i in items]),
                                    _ptrs([i[2] for i in items]), _ptrs(dvs), _ptrs(dgs),
                                    (ctypes.c_int * (2 * n))(*dims), L.ptr(sumsq), L.ptr(part)), 'vqa_wn_bwd_all')

@@ -125,7 +125,7 @@ class FlatAdamax:
         self.m = torch.zeros_like(flat.flat)
         self.u = torch.zeros_like(flat.flat)
         self.step_count = 0
-        self.part = torch.empty(256, device=dev, dtype=torch.float64)
+        self.part = torch.empty(1024, device=dev, dtype=torch.float64)
         self.sq = torch.zeros(1, device=dev)
         self.coef = torch.ones(1, device=dev)
         self.total_norm = torch.zeros(1, device=dev)     # device scalar: read it only when you want to sync

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
+
     const int tile = blockIdx.x, b = blockIdx.y, co0 = blockIdx.z * NB;
     const int ty = fastdiv(tile, a.tiles_x, a.inv_tx), tx = tile - ty * a.tiles_x;
     const int oy0 = ty * a.R, ox0 = tx * a.CW;
@@ -85,6 +86,11 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < NBF; ++n) acc[f][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    float bv[NBF][4];                                       // bias of this lane's channels, loaded up front
+#pragma unroll
+    for (int n = 0; n < NBF; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[n][e] = a.bias ? a.bias[co0 + n * 16 + q * 4 + e] : 0.f;
     // ---- staging plan.  Every thread moves up to NPV patch vectors and NWV weight vectors per channel chunk.  The
     // loads are branch-free (out-of-image / out-of-range lanes read a valid dummy address and are zeroed by a
     // select) so that all of a chunk's loads are in flight together, and the loads of chunk ch+1 are issued before
@@ -163,36 +169,41 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: + bias, store (lane owns 4 consecutive channels of one pixel), BN partial statistics
+    // ---- epilogue.  After the MFMAs a lane owns 4 channels of one pixel per (fragment, channel block): stored as
+    // they are, every store instruction scatters 8-byte pieces over 16 pixel rows (measured: the epilogue took 29 %
+    // of the workgroup's lifetime).  Instead each wave transposes its 64 pixels x NB channels through a private LDS
+    // region (the staging LDS is free after the last barrier) and writes whole pixel rows, 16 bytes per lane.
     T* y = static_cast<T*>(a.y);
+    constexpr int EROW = NB * (int)sizeof(T) + 16;          // LDS bytes per pixel row of the transpose
+    constexpr int VPR = NB * (int)sizeof(T) / 16;           // 16-byte vectors per pixel row
+    unsigned char* ew = smem + wave * 64 * EROW;
+    int* epix = reinterpret_cast<int*>(smem + 4 * 64 * EROW) + wave * 64;
     float s1[NBF][4], s2[NBF][4];
 #pragma unroll
     for (int n = 0; n < NBF; ++n)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s1[n][e] = s2[n][e] = 0.f;
 #pragma unroll
-    for (int n = 0; n < NBF; ++n) {
-        const int co = co0 + n * 16 + q * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
+    for (int f = 0; f < 4; ++f) {
+        const bool ok = opix[f] >= 0;
+        if (q == 0) epix[f * 16 + r] = opix[f];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = a.bias[co + e];
-        }
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            if (opix[f] < 0) continue;
+        for (int n = 0; n < NBF; ++n) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] = to_f32(from_f32<T>(acc[f][n][e] + bv[e]));  // statistics of what is stored
-                s1[n][e] += v[e];
-                s2[n][e] += v[e] * v[e];
+                v[e] = to_f32(from_f32<T>(acc[f][n][e] + bv[n][e]));  // statistics of what is stored
+                const float vs = ok ? v[e] : 0.f;
+                s1[n][e] += vs;
+                s2[n][e] += vs * vs;
             }
-            store_vec4<T>(y + (long)opix[f] * a.Cout + co, v);
+            store_vec4<T>(reinterpret_cast<T*>(ew + (f * 16 + r) * EROW) + n * 16 + q * 4, v);
         }
     }
     if (a.stats) {
-        float* red = reinterpret_cast<float*>(smem);  // [4 waves][NB][2]; staging LDS is free after the last sync
+        // [4 waves][NB][2] behind the transpose regions: the sums are ready before any global store is issued, so the
+        // barrier below does not wait for stores
+        float* red = reinterpret_cast<float*>(smem + 4 * 64 * EROW + 4 * 64 * 4);
 #pragma unroll
         for (int n = 0; n < NBF; ++n)
 #pragma unroll
@@ -209,6 +220,13 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
             const long blk = (long)b * gridDim.x + tile;
             a.stats[(blk * a.Cout + co0) * 2 + tid] = t;
         }
+    }
+#pragma unroll
+    for (int it = 0; it < VPR; ++it) {
+        const int idx = it * 64 + lane, p = idx / VPR, c = idx % VPR;
+        const uint4 vv = *reinterpret_cast<const uint4*>(ew + p * EROW + c * 16);
+        const int op = epix[p];
+        if (op >= 0) *reinterpret_cast<uint4*>(y + (long)op * a.Cout + co0 + c * (16 / (int)sizeof(T))) = vv;
     }
 }
 
@@ -393,6 +411,9 @@ size_t igemm_lds(const ConvArgs& a) {
     const int PPIX = (a.R + 2) * (a.CW + 2);
     size_t lds = (size_t)(PPIX * Cfg::PXB + 15) / 16 * 16 + (size_t)NBF * 16 * Cfg::WROWB + (size_t)NBF * 16 * 4;
     if (lds < (size_t)4 * NBF * 16 * 2 * sizeof(float)) lds = (size_t)4 * NBF * 16 * 2 * sizeof(float);
+    const size_t epi = (size_t)4 * 64 * (NBF * 16 * sizeof(T) + 16) + 4 * 64 * 4 +   // tile kernel's store transpose
+                       (size_t)4 * NBF * 16 * 2 * 4;                                   // + its statistics rows
+    if (lds < epi) lds = epi;
     return lds;
 }
 

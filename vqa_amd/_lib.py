@@ -36,8 +36,14 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _raw_stream():
+    """The current HIP stream of the current device as an integer handle (the C call torch's own extensions use:
+    ~0.3 us against ~9 us for torch.cuda.current_stream(); the step issues ~230 launches)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream())
 
 
 def check(status, what):
@@ -45,18 +51,23 @@ def check(status, what):
         raise VqaHipError(f'{what} failed with status {status}')
 
 
+_FN = {}
+
+
 def call(name, *args):
-    """Call an exported function: tensors -> device pointers, ints/floats passed by value, stream prepended."""
-    fn = getattr(lib(), name)
-    conv = [stream()]
-    for a in args:
-        if a is None or isinstance(a, torch.Tensor):
-            conv.append(ptr(a))
-        elif isinstance(a, float):
-            conv.append(ctypes.c_float(a))
-        else:
-            conv.append(ctypes.c_long(int(a)))   # x86-64: int and long params both read it correctly
-    check(fn(*conv), name)
+    """Call an exported function: tensors -> device pointers, ints/floats passed by value, stream prepended.
+    The ctypes prototype is built on the first call of each function (tensor / None -> void*, float -> float,
+    anything else -> long; x86-64: int and long parameters both read it correctly) and reused afterwards."""
+    fn = _FN.get(name)
+    if fn is None:
+        fn = getattr(lib(), name)
+        fn.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p if (a is None or isinstance(a, torch.Tensor)) else
+                                           (ctypes.c_float if isinstance(a, float) else ctypes.c_long) for a in args]
+        fn.restype = ctypes.c_int
+        _FN[name] = fn
+    status = fn(_raw_stream(), *[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args])
+    if status != 0:
+        raise VqaHipError(f'{name} failed with status {status}')
 
 
 def declared_symbols():

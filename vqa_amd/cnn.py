@@ -9,6 +9,7 @@ convolutions with BatchNorm statistics in the epilogue, fused BN+ReLU+pool apply
 precision: 'bf16' (bf16 activations/weights in the MFMA, fp32 accumulate, fp32 master weights and statistics)
 or 'fp32' (exact-f32 MFMA).  There is no CPU path: on a CPU tensor the module raises.
 """
+import functools
 import platform
 
 import torch
@@ -23,6 +24,7 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 CIN0_PAD = 16          # the 3 image channels are zero-padded to one MFMA k-group
 
 
+@functools.lru_cache(maxsize=None)
 def pick_tile(oh, ow, mt_max=256, patch_max=384):
     """(R, CW): output-tile rows x cols of one workgroup.  Fewest tiles first, then the smallest halo."""
     best = None

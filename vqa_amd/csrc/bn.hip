@@ -80,20 +80,26 @@ __global__ void bn_act_pool_fwd(const T* y, T* a, const float* scale, const floa
     const int CV = C / N;
     const int PH = pool ? H / 2 : H, PW = pool ? W / 2 : W;
     const long total = (long)B * PH * PW * CV;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cv = i % CV;
-        const long px = i / CV;
-        float sc[N], sh[N], o[N];
+    // CV is a power of two <= 32 and divides the grid stride: a thread keeps ONE channel vector, its 2N coefficients
+    // are loaded once (inside the loop they were 16 extra vector-memory instructions per 16 bytes of data)
+    const int cv = threadIdx.x % CV;
+    float sc[N], sh[N];
 #pragma unroll
-        for (int e = 0; e < N; ++e) { sc[e] = scale[cv * N + e]; sh[e] = shift[cv * N + e]; }
+    for (int e = 0; e < N; ++e) { sc[e] = scale[cv * N + e]; sh[e] = shift[cv * N + e]; }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long px = i / CV;
+        float o[N];
         if (!pool) {
             float v[N];
             Vec<T>::load(y + px * C + cv * N, v);
 #pragma unroll
             for (int e = 0; e < N; ++e) o[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
         } else {
-            const int pw = px % PW, ph = (px / PW) % PH;
-            const long b = px / ((long)PW * PH);
+            // 32-bit unsigned division (B*PH*PW < 2^32): a third of the instructions of the 64-bit one
+            const unsigned pxu = (unsigned)px, rowi = pxu / (unsigned)PW;
+            const int pw = (int)(pxu - rowi * (unsigned)PW);
+            const long b = rowi / (unsigned)PH;
+            const int ph = (int)(rowi - (unsigned)b * (unsigned)PH);
             const T* base = y + ((b * H + 2 * ph) * W + 2 * pw) * C + cv * N;
 #pragma unroll
             for (int e = 0; e < N; ++e) o[e] = 0.f;   // relu floor; for avg: running sum
@@ -141,8 +147,11 @@ __global__ __launch_bounds__(256) void bn_bwd(const T* y, const T* dout, T* dy, 
         Vec<T>::load(dout + px * C + cv * N, g);
         const T* ybase;
         if (pool) {
-            const int pw = px % PW, ph = (px / PW) % PH;
-            const long b = px / ((long)PW * PH);
+            // 32-bit unsigned division (B*PH*PW < 2^32): a third of the instructions of the 64-bit one
+            const unsigned pxu = (unsigned)px, rowi = pxu / (unsigned)PW;
+            const int pw = (int)(pxu - rowi * (unsigned)PW);
+            const long b = rowi / (unsigned)PH;
+            const int ph = (int)(rowi - (unsigned)b * (unsigned)PH);
             ybase = y + ((b * H + 2 * ph) * W + 2 * pw) * C + cv * N;
         } else {
             ybase = y + px * C + cv * N;
@@ -287,11 +296,11 @@ extern "C" int vqa_bn_act_pool_fwd(void* stream, int dtype, const void* y, void*
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long out_px = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
     if (dtype == VQA_BF16) {
-        if (C % 8) return VQA_ERR_ARG;
+        if (C % 8 || 256 % (C / 8)) return VQA_ERR_ARG;     // a thread keeps one channel vector (C/8 divides 256)
         hipLaunchKernelGGL(bn_act_pool_fwd<bf16>, dim3(grid_for(out_px * (C / 8), 256)), dim3(256), 0, s,
                            static_cast<const bf16*>(y), static_cast<bf16*>(a), scale, shift, B, H, W, C, pool);
     } else if (dtype == VQA_F32) {
-        if (C % 4) return VQA_ERR_ARG;
+        if (C % 4 || 256 % (C / 4)) return VQA_ERR_ARG;
         hipLaunchKernelGGL(bn_act_pool_fwd<float>, dim3(grid_for(out_px * (C / 4), 256)), dim3(256), 0, s,
                            static_cast<const float*>(y), static_cast<float*>(a), scale, shift, B, H, W, C, pool);
     } else {

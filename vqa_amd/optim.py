@@ -78,12 +78,14 @@ class GradBuckets:
     """Bucketed asynchronous gradient all-reduce (SUM) over torch.distributed (backend 'nccl' = RCCL on ROCm,
     'gloo' in the CPU tests)."""
 
-    def __init__(self, flat: FlatParams, group=None):
+    def __init__(self, flat: FlatParams, group=None, force=False):
+        """force=True arms the hooks and the all-reduces even in a 1-rank group (tests: the real RCCL path on one GPU)."""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.pending, self.handles = [], []
         self._left = []
-        if self.world > 1:
+        if self.active:
             # a bucket is ready when the LAST of its parameters has accumulated its gradient
             ends = [e for _, e in flat.bucket_ranges]
             self._bucket_idx = []
@@ -97,7 +99,7 @@ class GradBuckets:
     def reset(self):
         self.handles = []
         counts = [0] * len(self.flat.bucket_ranges)
-        if self.world > 1:
+        if self.active:
             for b in self._bucket_idx:
                 counts[b] += 1
         self._left = counts
@@ -148,11 +150,11 @@ class Trainer:
     """One reference training step (vqa_model.py:248-266) on the HIP path:
     zero_grad -> flip -> forward -> sum-BCE -> backward (-> bucketed all-reduce) -> clip 0.25 -> Adamax."""
 
-    def __init__(self, model, lr=2e-3, max_norm=0.25):
+    def __init__(self, model, lr=2e-3, max_norm=0.25, force_buckets=False):
         from .vqa_model import SoftScoreBCELoss
         self.model = model
         self.flat = FlatParams(model)
-        self.buckets = GradBuckets(self.flat)
+        self.buckets = GradBuckets(self.flat, force=force_buckets)
         self.opt = FlatAdamax(self.flat, lr=lr, max_norm=max_norm)
         self.criterion = SoftScoreBCELoss()
 
@@ -163,7 +165,7 @@ class Trainer:
         logits = self.model(images, questions)
         loss = self.criterion(logits, target)
         loss.backward()
-        if self.buckets.world == 1:
+        if not self.buckets.active:
             self.flat.collect()
         self.buckets.wait()
         self.opt.step()

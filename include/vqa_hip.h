@@ -32,7 +32,9 @@ int vqa_conv_pack(void* stream, int dtype, const float* w, void* out, int Cout, 
 
 /* The same for n (<= 24) weights in one launch: w / out are HOST arrays of device pointers, desc a host array of
  * n x 6 ints (Cout, Cin, CinP, CK, KP, dgrad). */
-int vqa_conv_pack_all(void* stream, int dtype, int n, const void* const* w, void* const* out, const int* desc);
+int vqa_conv_pack_all(void* stream, int dtype, int n, const void* const* w, void* const* out, const int* desc,
+                      const void* const* scale /* NULL, or per job NULL / [Cout] f32 folded into a forward slab:
+                                                  eval-mode BatchNorm, W' = W * gamma / sqrt(var + eps) */);
 
 /* nn.Conv2d(k=3, stride 1, padding=pad) forward (cnn.py:23-40) as implicit GEMM on MFMA; also the data gradient
  * when called on dy with a dgrad slab and pad' = 2 - pad.  y = conv(x) + bias.  R x CW (<= 256 pixels) is the output
@@ -41,7 +43,7 @@ int vqa_conv_pack_all(void* stream, int dtype, int n, const void* const* w, void
  * NULL) receives G rows of per-channel (sum, sum of squares) of y, [G][Cout][2], for the BatchNorm that follows. */
 int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked, void* y, const float* bias,
                     float* stats, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW,
-                    int G);
+                    int G, int relu /* 1: y = max(conv + bias, 0) - eval mode with the BatchNorm folded into w, bias */);
 int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW);
 
 /* First encoder layer, bf16 path: nn.Conv2d(3, 16, 3, padding=pad) (cnn.py:23) straight from the NCHW image
@@ -50,7 +52,8 @@ int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int OH, int OW, 
  * workgroups (<= tiles * B) walk the tiles, stats = [G][16][2] as in vqa_conv3x3_fwd.
  * _wgrad: dw [16][3][3][3] f32 from dy (NHWC bf16) and the image; part = [G][16][32] f32. */
 int vqa_conv3x3_first_fwd(void* stream, int in_dtype, const void* images, const float* w, void* y, const float* bias,
-                          float* stats, int B, int IH, int IW, int OH, int OW, int pad, int R, int CW, int G);
+                          float* stats, int B, int IH, int IW, int OH, int OW, int pad, int R, int CW, int G,
+                          const float* wscale /* NULL or [16]: folded into w */, int relu);
 int vqa_conv3x3_first_wgrad(void* stream, int in_dtype, const void* images, const void* dy, float* part, float* dw,
                             int G, int B, int IH, int IW, int OH, int OW, int pad, int R, int CW);
 

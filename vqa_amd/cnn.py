@@ -65,8 +65,9 @@ def pack_weights(w, cin_p, dtype, dgrad):
     return out
 
 
-def pack_all(jobs, dtype):
-    """jobs = [(w, cin_p, dgrad)]: every slab of the step in ONE launch; returns the slabs (views of one buffer)."""
+def pack_all(jobs, dtype, scales=None):
+    """jobs = [(w, cin_p, dgrad)]: every slab of the step in ONE launch; returns the slabs (views of one buffer).
+    scales[i] (optional, forward jobs) = per-output-channel factor folded into slab i (eval-mode BatchNorm)."""
     if not jobs:
         return []
     ct = L.ctypes
@@ -85,7 +86,9 @@ def pack_all(jobs, dtype):
         off += n
     n = len(jobs)
     L.check(L.lib().vqa_conv_pack_all(L.stream(), L.dt(buf), n, (ct.c_void_p * n)(*[j[0].data_ptr() for j in jobs]),
-                                      (ct.c_void_p * n)(*[o.data_ptr() for o in outs]), (ct.c_int * (6 * n))(*desc)),
+                                      (ct.c_void_p * n)(*[o.data_ptr() for o in outs]), (ct.c_int * (6 * n))(*desc),
+                                      None if scales is None else
+                                      (ct.c_void_p * n)(*[None if t is None else t.data_ptr() for t in scales])),
             'vqa_conv_pack_all')
     return outs
 
@@ -97,7 +100,7 @@ def _conv_tag(kind, B, OH, OW, cin_real, cout_real, x, y_elems_bytes, w_bytes):
                 bytes=float(x.numel() * x.element_size() + y_elems_bytes + w_bytes))
 
 
-def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd'):
+def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', relu=False):
     """x NHWC [B,IH,IW,Cin] -> y [B,OH,OW,Cout] (+ partial BN statistics rows)."""
     B, IH, IW, cin = x.shape
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
@@ -108,7 +111,8 @@ def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd'):
     cr = cin if cin_real is None else cin_real
     tag = _conv_tag(kind, B, OH, OW, cr, cout, x,
                     y.numel() * y.element_size(), wpk.numel() * wpk.element_size())
-    L.call('vqa_conv3x3_fwd', L.dt(x), x, wpk, y, bias, stats, B, IH, IW, cin, OH, OW, cout, pad, R, CW, G, tag=tag)
+    L.call('vqa_conv3x3_fwd', L.dt(x), x, wpk, y, bias, stats, B, IH, IW, cin, OH, OW, cout, pad, R, CW, G, int(relu),
+           tag=tag)
     return y, stats
 
 
@@ -172,7 +176,7 @@ def first_ok(images, w, dtype):
             images.shape[1] == 3 and images.dtype in (torch.float16, torch.float32, torch.bfloat16))
 
 
-def first_fwd(images, w, bias, pad, want_stats):
+def first_fwd(images, w, bias, pad, want_stats, wscale=None, relu=False):
     B, _, IH, IW = images.shape
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
     R, CW = pick_tile(OH, OW)
@@ -182,7 +186,7 @@ def first_fwd(images, w, bias, pad, want_stats):
     tag = dict(kind='first', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
                bytes=float(images.numel() * images.element_size() + y.numel() * 2 + w.numel() * 4))
     L.call('vqa_conv3x3_first_fwd', L.dt(images), images, w, y, bias, stats, B, IH, IW, OH, OW, pad, R, CW, G,
-           tag=tag)
+           wscale, int(relu), tag=tag)
     return y, stats
 
 
@@ -264,6 +268,46 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
     return dx, dw, dbias, dgamma, dbeta
 
 
+_POOL_ID = {}
+
+
+def _eval_forward(x, first, params, buffers, padding, pool_mode, dtype):
+    """Inference (BASELINE.json configs[3], "BN folded"): eval-mode BatchNorm is an affine map per channel, folded into
+    the conv - W' = W * scale[co] at packing time, b' = bias * scale + shift - so conv + BN + ReLU is ONE kernel with a
+    ReLU epilogue; only the pooled layers keep a second (pool-only) pass."""
+    dev = x.device
+    cinp = [CIN0_PAD] + list(CHANNELS[1:10])
+    coef = torch.empty(10, 3, 256, device=dev, dtype=torch.float32)          # scale, shift, folded bias per layer
+    for li in range(10):
+        w, bias, gamma, beta = params[4 * li: 4 * li + 4]
+        c = w.shape[0]
+        L.call('vqa_bn_eval_coeffs', c, gamma, beta, buffers[2 * li], buffers[2 * li + 1], BN_EPS, coef[li, 0],
+               coef[li, 1])
+    coef[:, 2] = coef[:, 1]
+    for li in range(10):
+        c = params[4 * li].shape[0]
+        coef[li, 2, :c].addcmul_(params[4 * li + 1], coef[li, 0, :c])        # b' = shift + bias * scale
+    jobs = [(params[4 * li], cinp[li], False) for li in range(10) if not (first and li == 0)]
+    scales = [coef[li, 0] for li in range(10) if not (first and li == 0)]
+    slabs = ([None] if first else []) + pack_all(jobs, dtype, scales)
+    key = str(dev)
+    if key not in _POOL_ID:
+        _POOL_ID[key] = (torch.ones(256, device=dev), torch.zeros(256, device=dev))
+    one, zero = _POOL_ID[key]
+    for li in range(10):
+        w = params[4 * li]
+        c = w.shape[0]
+        pad = padding if li in (0, 2, 4, 6) else 0
+        bf = coef[li, 2, :c]
+        if first and li == 0:
+            y, _ = first_fwd(x, w, bf, pad, False, wscale=coef[0, 0], relu=True)
+        else:
+            y, _ = conv_fwd(x, slabs[li], bf, c, pad, False, cin_real=w.shape[1], relu=True)
+        x = bn_act_pool(y, one, zero, pool_mode) if li % 2 == 1 else y       # relu(y) >= 0: pool-only pass
+    B, PH, PW, C = x.shape
+    return x.reshape(B, PH * PW, C).float()
+
+
 class _CnnFunction(torch.autograd.Function):
     """images [B,3,S,S] + the 40 parameters + 20 running buffers -> [B,k,256] fp32."""
 
@@ -273,6 +317,9 @@ class _CnnFunction(torch.autograd.Function):
         params, buffers = tensors[:40], tensors[40:]
         first = first_ok(images, params[0], dtype)
         x = images.contiguous() if first else to_nhwc(images, dtype)
+        if not training:
+            ctx.cfg = cfg
+            return _eval_forward(x, first, params, buffers, padding, pool_mode, dtype)
         saved, meta = [], []
         # every packed weight slab of the step (forward, and data-gradient when training) in one launch
         cinp = [CIN0_PAD] + list(CHANNELS[1:10])

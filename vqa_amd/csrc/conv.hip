@@ -31,6 +31,7 @@ struct ConvArgs {
     int B, IH, IW, Cin, OH, OW, Cout, pad;
     int R, CW, tiles_x, tiles_y;
     float inv_cw, inv_pw, inv_tx, inv_tiles;
+    int relu;           // epilogue: y = max(conv + bias, 0)  (eval mode with the BatchNorm folded into w / bias)
 };
 
 template <typename T, int CK> struct ConvCfg {
@@ -192,7 +193,9 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] = to_f32(from_f32<T>(acc[f][n][e] + bv[n][e]));  // statistics of what is stored
+                float pre = acc[f][n][e] + bv[n][e];
+                if (a.relu) pre = fmaxf(pre, 0.f);
+                v[e] = to_f32(from_f32<T>(pre));                       // statistics of what is stored
                 const float vs = ok ? v[e] : 0.f;
                 s1[n][e] += vs;
                 s2[n][e] += vs * vs;
@@ -373,7 +376,9 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = to_f32(from_f32<T>(acc[f][n][e] + bv[e]));  // statistics of what is stored
+                    float pre = acc[f][n][e] + bv[e];
+                    if (a.relu) pre = fmaxf(pre, 0.f);
+                    v[e] = to_f32(from_f32<T>(pre));                   // statistics of what is stored
                     const float vs = ok ? v[e] : 0.f;
                     s1[n][e] += vs;
                     s2[n][e] += vs * vs;
@@ -764,6 +769,7 @@ __global__ void conv_pack(const float* w, T* out, int Cout, int Cin, int CinP, i
 constexpr int PACK_MAX_JOBS = 24;
 struct PackJobs {
     const float* w[PACK_MAX_JOBS];
+    const float* scale[PACK_MAX_JOBS];   // per output channel (forward slabs only) or null: W' = W * scale[co]
     void* out[PACK_MAX_JOBS];
     int Cout[PACK_MAX_JOBS], Cin[PACK_MAX_JOBS], CinP[PACK_MAX_JOBS], CK[PACK_MAX_JOBS], KP[PACK_MAX_JOBS],
         dgrad[PACK_MAX_JOBS];
@@ -772,6 +778,7 @@ template <typename T>
 __global__ void conv_pack_all(PackJobs j) {
     const int b = blockIdx.y;
     const float* w = j.w[b];
+    const float* scale = j.scale[b];
     T* out = static_cast<T*>(j.out[b]);
     const int Cout = j.Cout[b], Cin = j.Cin[b], CinP = j.CinP[b], CK = j.CK[b], KP = j.KP[b], dgrad = j.dgrad[b];
     const int rows = dgrad ? CinP : Cout, red = dgrad ? Cout : CinP;
@@ -785,6 +792,7 @@ __global__ void conv_pack_all(PackJobs j) {
             const int tap = k / CK, c = ch * CK + k % CK;
             if (!dgrad) {
                 if (c < Cin) v = w[((long)row * Cin + c) * 9 + tap];
+                if (scale) v *= scale[row];
             } else {
                 if (row < Cin) v = w[((long)c * Cin + row) * 9 + (8 - tap)];
             }
@@ -817,14 +825,14 @@ __global__ void nchw_to_nhwc(const TI* in, T* out, int B, int C, int H, int W, i
 
 static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* wpacked, void* y, const float* bias,
                           float* stats, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW,
-                          int G, bool plan_only) {
+                          int G, bool plan_only, int relu = 0) {
     const int bad = plan_only ? -1 : VQA_ERR_ARG;
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || R * CW > 256 ||
         (R + 2) * (CW + 2) > 384 || B < 1)
         return bad;
     const int tx_ = (OW + CW - 1) / CW, ty_ = (OH + R - 1) / R;
     ConvArgs a{x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
-               1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_)};
+               1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), relu};
     if (dtype == VQA_BF16) {
         if (Cin % 32 == 0) return dispatch_nb<bf16, 32>(s, a, G, plan_only);
         if (Cin == 16) return dispatch_nb<bf16, 16>(s, a, G, plan_only);
@@ -836,9 +844,9 @@ static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* w
 
 extern "C" int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked, void* y,
                                const float* bias, float* stats, int B, int IH, int IW, int Cin, int OH, int OW,
-                               int Cout, int pad, int R, int CW, int G) {
+                               int Cout, int pad, int R, int CW, int G, int relu) {
     return conv_fwd_entry(static_cast<hipStream_t>(stream), dtype, x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW,
-                          Cout, pad, R, CW, G, false);
+                          Cout, pad, R, CW, G, false, relu);
 }
 
 // G for vqa_conv3x3_fwd: persistent workgroups per output-channel block = rows of `stats`; -1 = unsupported shape
@@ -916,9 +924,10 @@ extern "C" int vqa_conv_pack(void* stream, int dtype, const float* w, void* out,
 }
 
 // n jobs; w / out are HOST arrays of device pointers, desc is a host array of n x 6 ints
-// (Cout, Cin, CinP, CK, KP, dgrad): the arguments of n vqa_conv_pack calls, done by one launch.
+// (Cout, Cin, CinP, CK, KP, dgrad): the arguments of n vqa_conv_pack calls, done by one launch.  scale (may be NULL, or
+// hold NULLs) = per-output-channel factors folded into the forward slabs: eval-mode BatchNorm, W' = W * gamma/sigma.
 extern "C" int vqa_conv_pack_all(void* stream, int dtype, int n, const void* const* w, void* const* out,
-                                 const int* desc) {
+                                 const int* desc, const void* const* scale) {
     if (n < 1 || n > PACK_MAX_JOBS || !w || !out || !desc) return VQA_ERR_ARG;
     PackJobs j;
     long nmax = 0;
@@ -927,6 +936,8 @@ extern "C" int vqa_conv_pack_all(void* stream, int dtype, int n, const void* con
         const int rows = d[5] ? d[2] : d[0], red = d[5] ? d[0] : d[2];
         if (d[3] < 1 || red % d[3]) return VQA_ERR_ARG;
         j.w[i] = static_cast<const float*>(w[i]);
+        j.scale[i] = scale ? static_cast<const float*>(scale[i]) : nullptr;
+        if (j.scale[i] && d[5]) return VQA_ERR_ARG;                 // folding applies to forward slabs
         j.out[i] = out[i];
         j.Cout[i] = d[0]; j.Cin[i] = d[1]; j.CinP[i] = d[2]; j.CK[i] = d[3]; j.KP[i] = d[4]; j.dgrad[i] = d[5];
         const long ne = (long)(red / d[3]) * rows * d[4];

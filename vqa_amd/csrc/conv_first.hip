@@ -19,6 +19,8 @@ struct FirstArgs {
     int B, IH, IW, OH, OW, pad;
     int R, CW, tiles_x, tiles_y;
     float inv_cw, inv_pw, inv_tx, inv_tiles;
+    const float* wscale; // fwd: per-output-channel factor folded into the weights (eval-mode BatchNorm) or null
+    int relu;            // fwd: y = max(conv + bias, 0)
 };
 
 constexpr int PMAX = 384;                       // host bound on (R+2)*(CW+2)
@@ -94,12 +96,13 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
     PatchPlan pl;
     plan_patch(a, PW, PP, pl);
     // weight fragment (MFMA A operand: row = output channel r, k = 8q..8q+7), straight from the f32 master
+    const float wsc = a.wscale ? a.wscale[r] : 1.f;
     bf16x8 fw;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = 8 * q + j;
         const float wk = a.w[r * 27 + (k < 27 ? k : 26)];     // unconditional load, zeroed by the multiply
-        fw[j] = (bf16)(wk * (k < 27 ? 1.f : 0.f));
+        fw[j] = (bf16)(wk * (k < 27 ? wsc : 0.f));
     }
     int koff[8];
 #pragma unroll
@@ -161,7 +164,9 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = (bf16)(acc[e] + bv[e]);
+                    float pre = acc[e] + bv[e];
+                    if (a.relu) pre = fmaxf(pre, 0.f);
+                    o[e] = (bf16)pre;
                     const float v = ok ? (float)o[e] : 0.f;          // statistics of what is stored
                     s1[e] += v;
                     s2[e] += v * v;
@@ -328,8 +333,10 @@ bool first_args(FirstArgs& a, int B, int IH, int IW, int OH, int OW, int pad, in
 
 extern "C" int vqa_conv3x3_first_fwd(void* stream, int in_dtype, const void* images, const float* w, void* y,
                                      const float* bias, float* stats, int B, int IH, int IW, int OH, int OW, int pad,
-                                     int R, int CW, int G) {
+                                     int R, int CW, int G, const float* wscale, int relu) {
     FirstArgs a{images, w, static_cast<bf16*>(y), bias, stats};
+    a.wscale = wscale;
+    a.relu = relu;
     if (!images || !w || !y || !first_args(a, B, IH, IW, OH, OW, pad, R, CW)) return VQA_ERR_ARG;
     if (G < 1 || G > a.tiles_x * a.tiles_y * B) return VQA_ERR_ARG;
     size_t lds = (size_t)3 * (R + 2) * (CW + 2) * 2;
@@ -348,6 +355,8 @@ extern "C" int vqa_conv3x3_first_wgrad(void* stream, int in_dtype, const void* i
                                        float* dw, int G, int B, int IH, int IW, int OH, int OW, int pad, int R,
                                        int CW) {
     FirstArgs a{images, nullptr, static_cast<bf16*>(const_cast<void*>(dy)), nullptr, part};
+    a.wscale = nullptr;
+    a.relu = 0;
     if (!images || !dy || !part || !dw || G < 1 || !first_args(a, B, IH, IW, OH, OW, pad, R, CW)) return VQA_ERR_ARG;
     const int MTP = (R * CW + 31) / 32 * 32;
     if (G > a.tiles_x * a.tiles_y * B) return VQA_ERR_ARG;

@@ -1,5 +1,6 @@
 """GPU: the whole drop-in VQA module (HIP kernels through the C-ABI) against the golden vectors captured from the
 reference and against the oracle on the same synthetic inputs and weights."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -188,3 +189,25 @@ def test_sparse_targets_match_dense(tmp_path):
     a_d = float(ops.soft_accuracy_sum(logits.detach(), dense.cuda()))
     a_s = float(ops.soft_accuracy_sum(logits.detach(), (labels.cuda(), scores.cuda())))
     assert a_s == pytest.approx(a_d, abs=1e-6) and a_d > 0
+
+
+def test_softscore_targets_feed_the_loss_kernel():
+    """Annotations -> vqa_amd.softscore -> packed sparse targets -> HIP loss / accuracy == the dense rows the
+    reference's dataset would build (dataset.py:135-138) through the oracle's BCE."""
+    import json
+    import vqa_model
+    from oracle import vqa_oracle as O
+    from vqa_amd import ops, softscore as S
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'softscore.json')) as f:
+        gold = json.load(f)
+    a2l, l2a, train_t, _ = S.prepare(gold['train_annotations'], gold['val_annotations'])
+    kept, _, _ = S.drop_unanswered(train_t, list(range(len(train_t))))
+    labels, scores = S.pack_sparse(kept)
+    dense = torch.from_numpy(S.densify(kept, len(l2a)))
+    torch.manual_seed(5)
+    logits = (torch.randn(len(kept), len(l2a)) * 2).cuda()
+    loss = vqa_model.SoftScoreBCELoss()(logits, (torch.from_numpy(labels).cuda(), torch.from_numpy(scores).cuda()))
+    assert float(loss) == pytest.approx(float(O.bce_sum(logits.cpu(), dense)), rel=1e-5)
+    acc = float(ops.soft_accuracy_sum(logits, (torch.from_numpy(labels).cuda(), torch.from_numpy(scores).cuda())))
+    want = float(dense[torch.arange(len(kept)), logits.cpu().argmax(1)].sum())
+    assert acc == pytest.approx(want, abs=1e-5)

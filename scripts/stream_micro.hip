@@ -1,0 +1,164 @@
+// What streaming rate does this box give a BN-shaped kernel?  copy / read2 / read2+write over 418 MB tensors, by grid
+// size, unroll, load policy and WG->address mapping.   hipcc --offload-arch=gfx950 -O3 -o scripts/bin/stream_micro ...
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void copy_gs(const v4u* __restrict__ in, v4u* __restrict__ out, long n) {
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        v4u v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(in + i + u * stride) : in[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { if (NT) __builtin_nontemporal_store(v[u], out + i + u * stride); else out[i + u * stride] = v[u]; }
+    }
+    for (; i < n; i += stride) out[i] = in[i];
+}
+// each WG owns a contiguous chunk
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void copy_chunk(const v4u* __restrict__ in, v4u* __restrict__ out, long n) {
+    const long per = (n + gridDim.x - 1) / gridDim.x;
+    const long lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+    long i = lo + threadIdx.x;
+    for (; i + (U - 1) * 256 < hi; i += U * 256) {
+        v4u v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(in + i + u * 256) : in[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { if (NT) __builtin_nontemporal_store(v[u], out + i + u * 256); else out[i + u * 256] = v[u]; }
+    }
+    for (; i < hi; i += 256) out[i] = in[i];
+}
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void read2(const v4u* __restrict__ a, const v4u* __restrict__ b, v4u* out, long n) {
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    unsigned acc = 0;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        v4u v[U], w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = NT ? __builtin_nontemporal_load(a + i + u * stride) : a[i + u * stride];
+            w[u] = NT ? __builtin_nontemporal_load(b + i + u * stride) : b[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u].x ^ w[u].y ^ v[u].z ^ w[u].w;
+    }
+    if (acc == 0x12345678u) out[0] = v4u{acc, 0, 0, 0};
+}
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void read1(const v4u* __restrict__ a, v4u* out, long n) {
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    unsigned acc = 0;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        v4u v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(a + i + u * stride) : a[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x12345678u) out[0] = v4u{acc, 0, 0, 0};
+}
+// WG b owns elements [b*256*U, (b+1)*256*U): all loads first, then the stores; grid = n / (256 U), no loop
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void copy_wg(const v4u* __restrict__ in, v4u* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 * U + threadIdx.x;
+    v4u v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (i + u * 256 < n) v[u] = NT ? __builtin_nontemporal_load(in + i + u * 256) : in[i + u * 256];
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (i + u * 256 < n) { if (NT) __builtin_nontemporal_store(v[u], out + i + u * 256); else out[i + u * 256] = v[u]; }
+}
+// the same with a loop of P passes of U loads (chunk = 256*U*P elements)
+template <int U, int P, bool NT>
+__global__ __launch_bounds__(256) void read2_wg(const v4u* __restrict__ a, const v4u* __restrict__ b, v4u* out, long n) {
+    long i = (long)blockIdx.x * 256 * U * P + threadIdx.x;
+    unsigned acc = 0;
+    for (int p = 0; p < P; ++p, i += 256 * U) {
+        v4u v[U], w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long j = i + u * 256 < n ? i + u * 256 : 0;
+            v[u] = NT ? __builtin_nontemporal_load(a + j) : a[j];
+            w[u] = NT ? __builtin_nontemporal_load(b + j) : b[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u].x ^ w[u].y ^ v[u].z ^ w[u].w;
+    }
+    if (acc == 0x12345678u) out[0] = v4u{acc, 0, 0, 0};
+}
+__global__ void fill(v4u* p, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v4u{(unsigned)i, (unsigned)(i * 3), (unsigned)(i * 7), 1u};
+}
+
+template <typename F>
+static float timeit(F f, int reps = 10) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    f(); f();
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) f();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
+int main() {
+    const long bytes = 256L * 226 * 226 * 16 * 2;   // layer-1 activation, bf16
+    const long n = bytes / 16;
+    // several buffers so that consecutive launches do not hit the Infinity Cache (rotate over 1.7 GB)
+    constexpr int NB = 4;
+    v4u *in[NB], *in2[NB], *out[NB];
+    for (int i = 0; i < NB; ++i) {
+        CK(hipMalloc(&in[i], bytes)); CK(hipMalloc(&in2[i], bytes)); CK(hipMalloc(&out[i], bytes));
+        hipLaunchKernelGGL(fill, dim3(2048), dim3(256), 0, 0, in[i], n);
+        hipLaunchKernelGGL(fill, dim3(2048), dim3(256), 0, 0, in2[i], n);
+        hipLaunchKernelGGL(fill, dim3(2048), dim3(256), 0, 0, out[i], n);
+    }
+    CK(hipDeviceSynchronize());
+    int rot = 0;
+    const int grids[] = {512, 2048, (int)((n + 255) / 256)};
+#define RUN(name, kern, nbytes, ...)                                                              \
+    for (int g : grids) {                                                                          \
+        float ms = timeit([&] { rot = (rot + 1) % NB; hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, 0, __VA_ARGS__); }); \
+        printf("%-22s grid %7d  %.3f ms  %.2f TB/s\n", name, g, ms, (nbytes) / ms * 1e-9);    \
+    }
+#define RUNWG(name, kern, nbytes, per, ...)                                                       \
+    {                                                                                              \
+        const int g = (int)((n + (per) - 1) / (per));                                              \
+        float ms = timeit([&] { rot = (rot + 1) % NB; hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, 0, __VA_ARGS__); }); \
+        printf("%-22s grid %7d  %.3f ms  %.2f TB/s\n", name, g, ms, (nbytes) / ms * 1e-9);    \
+    }
+    RUNWG("copy_wg U1", (copy_wg<1, false>), 2.0 * bytes, 256, in[rot], out[rot], n)
+    RUNWG("copy_wg U2", (copy_wg<2, false>), 2.0 * bytes, 512, in[rot], out[rot], n)
+    RUNWG("copy_wg U4", (copy_wg<4, false>), 2.0 * bytes, 1024, in[rot], out[rot], n)
+    RUNWG("copy_wg U8", (copy_wg<8, false>), 2.0 * bytes, 2048, in[rot], out[rot], n)
+    RUNWG("copy_wg U4 nt", (copy_wg<4, true>), 2.0 * bytes, 1024, in[rot], out[rot], n)
+    RUNWG("copy_wg U8 nt", (copy_wg<8, true>), 2.0 * bytes, 2048, in[rot], out[rot], n)
+    RUNWG("read2_wg U2 P2", (read2_wg<2, 2, false>), 2.0 * bytes, 256 * 4, in[rot], in2[rot], out[rot], n)
+    RUNWG("read2_wg U2 P8", (read2_wg<2, 8, false>), 2.0 * bytes, 256 * 16, in[rot], in2[rot], out[rot], n)
+    RUNWG("read2_wg U2 P16", (read2_wg<2, 16, false>), 2.0 * bytes, 256 * 32, in[rot], in2[rot], out[rot], n)
+    RUNWG("read2_wg U4 P8", (read2_wg<4, 8, false>), 2.0 * bytes, 256 * 32, in[rot], in2[rot], out[rot], n)
+    RUNWG("read2_wg U1 P16", (read2_wg<1, 16, false>), 2.0 * bytes, 256 * 16, in[rot], in2[rot], out[rot], n)
+    RUNWG("read2_wg U2 P16 nt", (read2_wg<2, 16, true>), 2.0 * bytes, 256 * 32, in[rot], in2[rot], out[rot], n)
+    RUNWG("read2_wg U2 P64 nt", (read2_wg<2, 64, true>), 2.0 * bytes, 256 * 128, in[rot], in2[rot], out[rot], n)
+    RUNWG("read2_wg U2 P64", (read2_wg<2, 64, false>), 2.0 * bytes, 256 * 128, in[rot], in2[rot], out[rot], n)
+    RUN("copy_gs U1", (copy_gs<1, false>), 2.0 * bytes, in[rot], out[rot], n)
+    RUN("copy_gs U4", (copy_gs<4, false>), 2.0 * bytes, in[rot], out[rot], n)
+    RUN("copy_gs U4 nt", (copy_gs<4, true>), 2.0 * bytes, in[rot], out[rot], n)
+    RUN("copy_chunk U4", (copy_chunk<4, false>), 2.0 * bytes, in[rot], out[rot], n)
+    RUN("copy_chunk U4 nt", (copy_chunk<4, true>), 2.0 * bytes, in[rot], out[rot], n)
+    RUN("read1 U4", (read1<4, false>), 1.0 * bytes, in[rot], out[rot], n)
+    RUN("read1 U4 nt", (read1<4, true>), 1.0 * bytes, in[rot], out[rot], n)
+    RUN("read2 U1", (read2<1, false>), 2.0 * bytes, in[rot], in2[rot], out[rot], n)
+    RUN("read2 U2", (read2<2, false>), 2.0 * bytes, in[rot], in2[rot], out[rot], n)
+    RUN("read2 U2 nt", (read2<2, true>), 2.0 * bytes, in[rot], in2[rot], out[rot], n)
+    return 0;
+}

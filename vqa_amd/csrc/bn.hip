@@ -11,21 +11,7 @@
 
 namespace {
 
-template <typename T> struct Vec {
-    static constexpr int N = 16 / sizeof(T);
-    static __device__ __forceinline__ void load(const T* p, float* f) {
-        uint4 v = *reinterpret_cast<const uint4*>(p);
-        const T* e = reinterpret_cast<const T*>(&v);
-#pragma unroll
-        for (int i = 0; i < N; ++i) f[i] = to_f32(e[i]);
-    }
-    static __device__ __forceinline__ void store(T* p, const float* f) {
-        T e[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) e[i] = from_f32<T>(f[i]);
-        *reinterpret_cast<uint4*>(p) = *reinterpret_cast<uint4*>(e);
-    }
-};
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 // One workgroup per channel: sums the conv epilogue's partial rows (a few hundred to a few thousand: one per
 // persistent conv workgroup) in fp64 in a fixed order, then produces the BN coefficients and running statistics.
@@ -72,146 +58,199 @@ __global__ void bn_eval_coeffs(int C, const float* gamma, const float* beta, con
     shift[c] = beta[c] - running_mean[c] * sc;
 }
 
-// pool: 0 none, 1 max, 2 avg.  One thread = one OUTPUT pixel x one 16-byte channel vector.
-template <typename T>
-__global__ void bn_act_pool_fwd(const T* y, T* a, const float* scale, const float* shift, int B, int H, int W, int C,
-                                int pool) {
-    constexpr int N = Vec<T>::N;
-    const int CV = C / N;
-    const int PH = pool ? H / 2 : H, PW = pool ? W / 2 : W;
-    const long total = (long)B * PH * PW * CV;
-    // CV is a power of two <= 32 and divides the grid stride: a thread keeps ONE channel vector, its 2N coefficients
-    // are loaded once (inside the loop they were 16 extra vector-memory instructions per 16 bytes of data)
-    const int cv = threadIdx.x % CV;
-    float sc[N], sh[N];
+// ---- work distribution of the streaming kernels.  An item = one OUTPUT pixel x one 16-byte channel vector; item i
+// lives at element offset i*N of an un-pooled tensor.  Workgroup b owns the contiguous items [b*CH, (b+1)*CH),
+// CH = 256*U*passes: `passes` rounds of U independent items per thread (thread t takes base + u*256 + t), all loads of
+// a round issued before its first store.  Measured on MI355X with 418 MB tensors (scripts/stream_micro.hip): contiguous
+// chunks per workgroup copy at 6.1-6.2 TB/s and read at 6.2 (6.8 with non-temporal loads), where the usual "cap the
+// grid at 2048 and grid-stride" loop gets 4.2-5.0 (copy) and 5.5 (read).  256 % CV == 0, so a thread keeps one channel
+// vector and its coefficients for its whole chunk.
+constexpr int kFwdU = 4, kFwdPoolU = 2, kBwdU = 2, kBwdPoolU = 1;
+
+template <typename T, bool NT> struct Stream {
+    static constexpr int N = 16 / sizeof(T);
+    static __device__ __forceinline__ void load(const T* p, float* f) {
+        const v4u* q = reinterpret_cast<const v4u*>(p);
+        const v4u v = NT ? __builtin_nontemporal_load(q) : *q;
+        const T* e = reinterpret_cast<const T*>(&v);
 #pragma unroll
-    for (int e = 0; e < N; ++e) { sc[e] = scale[cv * N + e]; sh[e] = shift[cv * N + e]; }
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long px = i / CV;
-        float o[N];
-        if (!pool) {
-            float v[N];
-            Vec<T>::load(y + px * C + cv * N, v);
-#pragma unroll
-            for (int e = 0; e < N; ++e) o[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
-        } else {
-            // 32-bit unsigned division (B*PH*PW < 2^32): a third of the instructions of the 64-bit one
-            const unsigned pxu = (unsigned)px, rowi = pxu / (unsigned)PW;
-            const int pw = (int)(pxu - rowi * (unsigned)PW);
-            const long b = rowi / (unsigned)PH;
-            const int ph = (int)(rowi - (unsigned)b * (unsigned)PH);
-            const T* base = y + ((b * H + 2 * ph) * W + 2 * pw) * C + cv * N;
-#pragma unroll
-            for (int e = 0; e < N; ++e) o[e] = 0.f;   // relu floor; for avg: running sum
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float v[N];
-                Vec<T>::load(base + ((long)(k >> 1) * W + (k & 1)) * C, v);
-#pragma unroll
-                for (int e = 0; e < N; ++e) {
-                    const float z = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
-                    o[e] = pool == 1 ? fmaxf(o[e], z) : o[e] + z;
-                }
-            }
-            if (pool == 2) {
-#pragma unroll
-                for (int e = 0; e < N; ++e) o[e] *= 0.25f;
-            }
-        }
-        Vec<T>::store(a + px * C + cv * N, o);
+        for (int i = 0; i < N; ++i) f[i] = to_f32(e[i]);
     }
+    static __device__ __forceinline__ void store(T* p, const float* f) {
+        T e[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) e[i] = from_f32<T>(f[i]);
+        const v4u v = *reinterpret_cast<const v4u*>(e);
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(p)); else *reinterpret_cast<v4u*>(p) = v;
+    }
+};
+template <int N> __device__ __forceinline__ void coeffs(const float* src, int cv, float* dst) {
+#pragma unroll
+    for (int e = 0; e < N; e += 4) *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(src + cv * N + e);
+}
+// top-left element offset of the 2x2 window of pooled pixel `px` (32-bit divisions: B*PH*PW < 2^32)
+__device__ __forceinline__ long window_base(unsigned px, int PH, int PW, int H, int W, int C) {
+    const unsigned rowi = px / (unsigned)PW;
+    const int pw = (int)(px - rowi * (unsigned)PW);
+    const long b = rowi / (unsigned)PH;
+    const int ph = (int)(rowi - (unsigned)b * (unsigned)PH);
+    return ((b * H + 2 * ph) * W + 2 * pw) * C;
 }
 
-// dz for the (up to) 4 positions of one output pixel.  Max pool: the gradient goes to the first maximum of
-// relu(z) in window order (ATen's choice); a window whose maximum is 0 passes nothing (relu' = 0 there).
-template <typename T, bool APPLY, int pool>
-__global__ __launch_bounds__(256) void bn_bwd(const T* y, const T* dout, T* dy, const float* scale, const float* shift,
-                                              const float* mean, const float* invstd, const float* c1, const float* c2,
-                                              float* part, int B, int H, int W, int C) {
-    constexpr int N = Vec<T>::N;
-    const int CV = C / N;                       // channel vectors; power of two <= 64
-    const int PH = pool ? H / 2 : H, PW = pool ? W / 2 : W;
-    const long npx = (long)B * PH * PW;
+// a = pool(relu(scale*y + shift)).  pool: 0 none, 1 max, 2 avg.
+template <typename T, int POOL, bool NT>
+__global__ __launch_bounds__(256) void bn_act_pool_fwd(const T* __restrict__ y, T* __restrict__ a,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       int B, int H, int W, int C, int passes) {
+    using S = Stream<T, NT>;
+    constexpr int N = S::N, U = POOL ? kFwdPoolU : kFwdU;
+    const int CV = C / N;
+    const int PH = POOL ? H / 2 : H, PW = POOL ? W / 2 : W;
+    const long total = (long)B * PH * PW * CV;
     const int cv = threadIdx.x % CV;
-    const int slot = threadIdx.x / CV, nslot = blockDim.x / CV;
-    float sc[N], sh[N], mu[N], is[N], k1[N], k2[N], a1[N], a2[N];
+    float sc[N], sh[N];
+    coeffs<N>(scale, cv, sc);
+    coeffs<N>(shift, cv, sh);
+    long i = (long)blockIdx.x * (256 * U) * passes + threadIdx.x;
+    for (int p = 0; p < passes; ++p, i += 256 * U) {
+        if (i >= total) break;
+        if (POOL == 0) {
+            float v[U][N];
 #pragma unroll
-    for (int e = 0; e < N; ++e) {
-        sc[e] = scale[cv * N + e]; sh[e] = shift[cv * N + e]; mu[e] = mean[cv * N + e]; is[e] = invstd[cv * N + e];
-        if (APPLY) { k1[e] = c1[cv * N + e]; k2[e] = c2[cv * N + e]; }
-        a1[e] = a2[e] = 0.f;
-    }
-    constexpr int np = pool ? 4 : 1;
-    for (long px = (long)blockIdx.x * nslot + slot; px < npx; px += (long)gridDim.x * nslot) {
-        float g[N];
-        Vec<T>::load(dout + px * C + cv * N, g);
-        const T* ybase;
-        if (pool) {
-            // 32-bit unsigned division (B*PH*PW < 2^32): a third of the instructions of the 64-bit one
-            const unsigned pxu = (unsigned)px, rowi = pxu / (unsigned)PW;
-            const int pw = (int)(pxu - rowi * (unsigned)PW);
-            const long b = rowi / (unsigned)PH;
-            const int ph = (int)(rowi - (unsigned)b * (unsigned)PH);
-            ybase = y + ((b * H + 2 * ph) * W + 2 * pw) * C + cv * N;
-        } else {
-            ybase = y + px * C + cv * N;
-        }
-        float v[np][N], z[np][N];
-#pragma unroll
-        for (int k = 0; k < np; ++k) {
-            Vec<T>::load(ybase + ((long)(k >> 1) * W + (k & 1)) * C, v[k]);
-#pragma unroll
-            for (int e = 0; e < N; ++e) z[k][e] = fmaf(v[k][e], sc[e], sh[e]);
-        }
-#pragma unroll
-        for (int k = 0; k < np; ++k) {
-            float dz[N];
-#pragma unroll
-            for (int e = 0; e < N; ++e) {
-                float d;
-                if (pool == 0) {
-                    d = z[0][e] > 0.f ? g[e] : 0.f;
-                } else if (pool == 2) {
-                    d = z[k][e] > 0.f ? 0.25f * g[e] : 0.f;
-                } else {
-                    const float m = fmaxf(fmaxf(z[0][e], z[1 % np][e]), fmaxf(z[2 % np][e], z[3 % np][e]));
-                    bool first = z[k][e] == m;
-#pragma unroll
-                    for (int j = 0; j < k; ++j) first = first && (z[j][e] != m);
-                    d = (m > 0.f && first) ? g[e] : 0.f;
-                }
-                dz[e] = d;
+            for (int u = 0; u < U; ++u) {           // out-of-range items re-read the last one (branch-free loads)
+                const long j = i + u * 256 < total ? i + u * 256 : total - 1;
+                S::load(y + j * N, v[u]);
             }
-            if (APPLY) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) v[u][e] = fmaxf(fmaf(v[u][e], sc[e], sh[e]), 0.f);
+                if (i + u * 256 < total) S::store(a + (i + u * 256) * N, v[u]);
+            }
+        } else {
+            float v[U][4][N];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long j = i + u * 256 < total ? i + u * 256 : total - 1;
+                const T* base = y + window_base((unsigned)(j / CV), PH, PW, H, W, C) + cv * N;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) S::load(base + ((long)(k >> 1) * W + (k & 1)) * C, v[u][k]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
                 float o[N];
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
-                    const float xh = (v[k][e] - mu[e]) * is[e];
-                    o[e] = sc[e] * (dz[e] - k1[e] - xh * k2[e]);
+                    float acc = 0.f;                // relu floor; for avg: running sum
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float z = fmaxf(fmaf(v[u][k][e], sc[e], sh[e]), 0.f);
+                        acc = POOL == 1 ? fmaxf(acc, z) : acc + z;
+                    }
+                    o[e] = POOL == 2 ? acc * 0.25f : acc;
                 }
-                Vec<T>::store(dy + (ybase - y) + ((long)(k >> 1) * W + (k & 1)) * C, o);
-            } else {
+                if (i + u * 256 < total) S::store(a + (i + u * 256) * N, o);
+            }
+        }
+    }
+}
+
+// BatchNorm backward.  dz for the (up to) 4 positions of one output pixel: max pool sends the gradient to the first
+// maximum of relu(z) in window order (ATen's choice); a window whose maximum is 0 passes nothing (relu' = 0 there).
+//   APPLY = false: partial sums of dz and dz*xhat, one row of `part` per workgroup
+//   APPLY = true : dy = scale * (dz - c1 - xhat*c2)
+template <typename T, bool APPLY, int pool, bool NT>
+__global__ __launch_bounds__(256) void bn_bwd(const T* __restrict__ y, const T* __restrict__ dout, T* __restrict__ dy,
+                                              const float* scale, const float* shift, const float* mean,
+                                              const float* invstd, const float* c1, const float* c2,
+                                              float* __restrict__ part, int B, int H, int W, int C, int passes) {
+    using S = Stream<T, NT>;
+    constexpr int N = S::N, U = pool ? kBwdPoolU : kBwdU;
+    const int CV = C / N;                       // channel vectors; power of two <= 64
+    const int PH = pool ? H / 2 : H, PW = pool ? W / 2 : W;
+    const long total = (long)B * PH * PW * CV;
+    const int cv = threadIdx.x % CV;
+    float sc[N], sh[N], mu[N], is[N], k1[N], k2[N], a1[N], a2[N];
+    coeffs<N>(scale, cv, sc);
+    coeffs<N>(shift, cv, sh);
+    coeffs<N>(mean, cv, mu);
+    coeffs<N>(invstd, cv, is);
+    if (APPLY) { coeffs<N>(c1, cv, k1); coeffs<N>(c2, cv, k2); }
+#pragma unroll
+    for (int e = 0; e < N; ++e) a1[e] = a2[e] = 0.f;
+    constexpr int np = pool ? 4 : 1;
+    long i = (long)blockIdx.x * (256 * U) * passes + threadIdx.x;
+    for (int p = 0; p < passes; ++p, i += 256 * U) {
+        if (i >= total) break;
+        float g[U][N], v[U][np][N];
+        long off[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long j = i + u * 256 < total ? i + u * 256 : total - 1;
+            S::load(dout + j * N, g[u]);
+            off[u] = pool ? window_base((unsigned)(j / CV), PH, PW, H, W, C) + cv * N : j * N;
+#pragma unroll
+            for (int k = 0; k < np; ++k) S::load(y + off[u] + ((long)(k >> 1) * W + (k & 1)) * C, v[u][k]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = i + u * 256 < total;
+            float z[np][N];
+#pragma unroll
+            for (int k = 0; k < np; ++k)
+#pragma unroll
+                for (int e = 0; e < N; ++e) z[k][e] = fmaf(v[u][k][e], sc[e], sh[e]);
+#pragma unroll
+            for (int k = 0; k < np; ++k) {
+                float dz[N];
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
-                    a1[e] += dz[e];
-                    a2[e] += dz[e] * ((v[k][e] - mu[e]) * is[e]);
+                    float d;
+                    if (pool == 0) {
+                        d = z[0][e] > 0.f ? g[u][e] : 0.f;
+                    } else if (pool == 2) {
+                        d = z[k][e] > 0.f ? 0.25f * g[u][e] : 0.f;
+                    } else {
+                        const float m = fmaxf(fmaxf(z[0][e], z[1 % np][e]), fmaxf(z[2 % np][e], z[3 % np][e]));
+                        bool first = z[k][e] == m;
+#pragma unroll
+                        for (int j = 0; j < k; ++j) first = first && (z[j][e] != m);
+                        d = (m > 0.f && first) ? g[u][e] : 0.f;
+                    }
+                    dz[e] = live ? d : 0.f;
+                }
+                if (APPLY) {
+                    float o[N];
+#pragma unroll
+                    for (int e = 0; e < N; ++e) {
+                        const float xh = (v[u][k][e] - mu[e]) * is[e];
+                        o[e] = sc[e] * (dz[e] - k1[e] - xh * k2[e]);
+                    }
+                    if (live) S::store(dy + off[u] + ((long)(k >> 1) * W + (k & 1)) * C, o);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < N; ++e) {
+                        a1[e] += dz[e];
+                        a2[e] += dz[e] * ((v[u][k][e] - mu[e]) * is[e]);
+                    }
                 }
             }
         }
     }
     if (APPLY && pool) {
         // floor-mode pooling drops the last row / column of an odd map: dz = 0 there, dy still gets the mean terms
+        const int nslot = 256 / CV, slot = threadIdx.x / CV;
         const int lw = (W & 1) ? H : 0, lh = (H & 1) ? (W - (W & 1)) : 0, nl = lw + lh;
-        for (long i = (long)blockIdx.x * nslot + slot; i < (long)B * nl; i += (long)gridDim.x * nslot) {
-            const long b = i / nl;
-            const int j = i % nl;
+        for (long t = (long)blockIdx.x * nslot + slot; t < (long)B * nl; t += (long)gridDim.x * nslot) {
+            const long b = t / nl;
+            const int j = t % nl;
             const int h = j < lw ? j : H - 1, w = j < lw ? W - 1 : j - lw;
-            const long off = ((b * H + h) * W + w) * C + cv * N;
-            float v[N], o[N];
-            Vec<T>::load(y + off, v);
+            const long o1 = ((b * H + h) * W + w) * C + cv * N;
+            float vv[N], o[N];
+            S::load(y + o1, vv);
 #pragma unroll
-            for (int e = 0; e < N; ++e) o[e] = sc[e] * (-k1[e] - (v[e] - mu[e]) * is[e] * k2[e]);
-            Vec<T>::store(dy + off, o);
+            for (int e = 0; e < N; ++e) o[e] = sc[e] * (-k1[e] - (vv[e] - mu[e]) * is[e] * k2[e]);
+            S::store(dy + o1, o);
         }
     }
     if (!APPLY) {
@@ -236,9 +275,9 @@ __global__ __launch_bounds__(256) void bn_bwd(const T* y, const T* dout, T* dy, 
         }
         __syncthreads();
         // waves hold the same channels when CV <= 64 (CV divides 64): sum the 4 waves in fixed order
-        for (int i = threadIdx.x; i < C * 2; i += blockDim.x) {
-            const float t = rw[i] + rw[per_wave + i] + rw[2 * per_wave + i] + rw[3 * per_wave + i];
-            part[(long)blockIdx.x * C * 2 + i] = t;
+        for (int t = threadIdx.x; t < C * 2; t += blockDim.x) {
+            const float s4 = rw[t] + rw[per_wave + t] + rw[2 * per_wave + t] + rw[3 * per_wave + t];
+            part[(long)blockIdx.x * C * 2 + t] = s4;
         }
     }
 }
@@ -266,11 +305,6 @@ __global__ void bn_bwd_finalize(const float* part, int rows, int C, double count
     }
 }
 
-int grid_for(long items, int per_block) {
-    long g = (items + per_block - 1) / per_block;
-    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
-}
-
 }  // namespace
 
 extern "C" int vqa_bn_finalize(void* stream, const float* part, int rows, int C, double count, const float* gamma,
@@ -291,50 +325,85 @@ extern "C" int vqa_bn_eval_coeffs(void* stream, int C, const float* gamma, const
     return VQA_OK;
 }
 
+// ---- launch geometry of the streaming kernels (see the comment above bn_act_pool_fwd)
+static int grid_of(long total, int U, int passes) {
+    const long per = 256L * U * passes;
+    return (int)((total + per - 1) / per);
+}
+// rounds per workgroup that keep the grid (= rows of partial sums for the reduce pass) at <= max_grid
+static int passes_for(long total, int U, int max_grid) {
+    const long g = (total + 256L * U - 1) / (256L * U);
+    const long p = (g + max_grid - 1) / max_grid;
+    return (int)(p < 1 ? 1 : p);
+}
+// Non-temporal loads / stores once a launch moves more than the 256 MB Infinity Cache can keep for the next kernel
+// anyway; below that, plain accesses leave the tensors on die for their consumer.  Measured per layer (B=256, bf16):
+// forward 226x226x16 0.155 -> 0.138 ms (6.1 TB/s), reduce 114x114x32 0.103 -> 0.077 ms; the POOLED apply pass is the
+// exception (224x224x16: 0.160 plain, 0.205 non-temporal): each of its store instructions fills half of every 64-byte
+// line (the even or the odd pixels of a row), which a write-back L2 merges and a streaming store cannot.
+static bool use_nt(double bytes) { return bytes > 256e6; }
+constexpr int kReduceRows = 4096;   // 2048: reduce pass 3 % slower, 16384: 8 % slower (more partial rows to finalize)
+
 extern "C" int vqa_bn_act_pool_fwd(void* stream, int dtype, const void* y, void* a, const float* scale,
                                    const float* shift, int B, int H, int W, int C, int pool) {
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (pool < 0 || pool > 2 || (dtype != VQA_BF16 && dtype != VQA_F32)) return VQA_ERR_ARG;
+    const int N = dtype == VQA_BF16 ? 8 : 4, esz = 16 / N;
+    if (C % N || 256 % (C / N)) return VQA_ERR_ARG;         // a thread keeps one channel vector (C/N divides 256)
     const long out_px = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
-    if (dtype == VQA_BF16) {
-        if (C % 8 || 256 % (C / 8)) return VQA_ERR_ARG;     // a thread keeps one channel vector (C/8 divides 256)
-        hipLaunchKernelGGL(bn_act_pool_fwd<bf16>, dim3(grid_for(out_px * (C / 8), 256)), dim3(256), 0, s,
-                           static_cast<const bf16*>(y), static_cast<bf16*>(a), scale, shift, B, H, W, C, pool);
-    } else if (dtype == VQA_F32) {
-        if (C % 4 || 256 % (C / 4)) return VQA_ERR_ARG;
-        hipLaunchKernelGGL(bn_act_pool_fwd<float>, dim3(grid_for(out_px * (C / 4), 256)), dim3(256), 0, s,
-                           static_cast<const float*>(y), static_cast<float*>(a), scale, shift, B, H, W, C, pool);
-    } else {
-        return VQA_ERR_ARG;
-    }
+    const long total = out_px * (C / N);
+    if (total <= 0) return VQA_ERR_ARG;
+    const int U = pool ? kFwdPoolU : kFwdU, passes = 1;
+    const bool nt = use_nt(((double)B * H * W * C + (double)out_px * C) * esz);
+    const dim3 grid(grid_of(total, U, passes));
+#define GO(T, P, NT) hipLaunchKernelGGL((bn_act_pool_fwd<T, P, NT>), grid, dim3(256), 0, s, static_cast<const T*>(y), \
+                                        static_cast<T*>(a), scale, shift, B, H, W, C, passes)
+#define GN(T, P) do { if (nt) GO(T, P, true); else GO(T, P, false); } while (0)
+#define GP(T) do { if (pool == 0) GN(T, 0); else if (pool == 1) GN(T, 1); else GN(T, 2); } while (0)
+    if (dtype == VQA_BF16) GP(bf16); else GP(float);
+#undef GP
+#undef GN
+#undef GO
     CHECK_LAUNCH();
     return VQA_OK;
 }
 
+static int bwd_geometry(int dtype, int B, int H, int W, int C, int pool, int apply, int* passes) {
+    const int N = dtype == VQA_BF16 ? 8 : 4;
+    const long total = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C / N);
+    const int U = pool ? kBwdPoolU : kBwdU;
+    *passes = apply ? 1 : passes_for(total, U, kReduceRows);
+    return grid_of(total, U, *passes);
+}
+
 // rows of `part` the reduce pass writes (= its grid size)
 extern "C" int vqa_bn_bwd_rows(int dtype, int B, int H, int W, int C, int pool) {
-    const int N = dtype == VQA_BF16 ? 8 : 4;
-    const int CV = C / N;
-    const long npx = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
-    return grid_for(npx, (256 / CV) * 4);
+    int passes;
+    return bwd_geometry(dtype, B, H, W, C, pool, 0, &passes);
 }
 
 extern "C" int vqa_bn_bwd(void* stream, int dtype, int apply, const void* y, const void* dout, void* dy,
                           const float* scale, const float* shift, const float* mean, const float* invstd,
                           const float* c1, const float* c2, float* part, int B, int H, int W, int C, int pool) {
-    const int N = dtype == VQA_BF16 ? 8 : 4;
+    if (dtype != VQA_BF16 && dtype != VQA_F32) return VQA_ERR_ARG;
+    const int N = dtype == VQA_BF16 ? 8 : 4, esz = 16 / N;
     const int CV = C / N;
-    if (C % N || CV > 64 || (CV & (CV - 1))) return VQA_ERR_ARG;
+    if (C % N || CV > 64 || (CV & (CV - 1)) || pool < 0 || pool > 2 || C > 256) return VQA_ERR_ARG;
+    if (apply ? (!dy || !c1 || !c2) : !part) return VQA_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = vqa_bn_bwd_rows(dtype, B, H, W, C, pool);
-#define GO(T, AP, P) hipLaunchKernelGGL((bn_bwd<T, AP, P>), dim3(grid), dim3(256), 0, s, static_cast<const T*>(y), \
-                                        static_cast<const T*>(dout), static_cast<T*>(dy), scale, shift, mean, invstd, \
-                                        c1, c2, part, B, H, W, C)
-#define GP(T, AP) do { if (pool == 0) GO(T, AP, 0); else if (pool == 1) GO(T, AP, 1); else GO(T, AP, 2); } while (0)
-    if (pool < 0 || pool > 2 || C > 256) return VQA_ERR_ARG;
+    int passes;
+    const dim3 grid(bwd_geometry(dtype, B, H, W, C, pool, apply, &passes));
+    const double ny = (double)B * H * W * C, nd = pool ? ny / 4 : ny;
+    const bool nt = use_nt((ny + nd + (apply ? ny : 0.0)) * esz) && !(apply && pool);
+#define GO(T, AP, P, NT) hipLaunchKernelGGL((bn_bwd<T, AP, P, NT>), grid, dim3(256), 0, s, static_cast<const T*>(y), \
+                                            static_cast<const T*>(dout), static_cast<T*>(dy), scale, shift, mean, \
+                                            invstd, c1, c2, part, B, H, W, C, passes)
+#define GN(T, AP, P) do { if (nt) GO(T, AP, P, true); else GO(T, AP, P, false); } while (0)
+#define GP(T, AP) do { if (pool == 0) GN(T, AP, 0); else if (pool == 1) GN(T, AP, 1); else GN(T, AP, 2); } while (0)
     if (dtype == VQA_BF16) { if (apply) GP(bf16, true); else GP(bf16, false); }
-    else if (dtype == VQA_F32) { if (apply) GP(float, true); else GP(float, false); }
-    else return VQA_ERR_ARG;
+    else { if (apply) GP(float, true); else GP(float, false); }
 #undef GP
+#undef GN
 #undef GO
     CHECK_LAUNCH();
     return VQA_OK;

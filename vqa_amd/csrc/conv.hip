@@ -13,6 +13,7 @@
 //                   4-byte reads.  Partials per workgroup, summed in fixed order by conv3x3_wgrad_reduce.
 //   pack kernels    torch-layout f32 weights [Cout][Cin][3][3] -> k-contiguous slabs for fwd and dgrad.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -68,11 +69,15 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     const T* x = static_cast<const T*>(a.x);
     const T* w = static_cast<const T*>(a.w);
 
-    // per-fragment pixel decode (4 fragments of 16 consecutive tile pixels per wave)
+    // per-fragment pixel decode.  The tile's fragments of 16 consecutive pixels are dealt to the waves round-robin
+    // (fragment f of wave w = fragment 4f + w of the tile) and a wave skips the MFMAs of fragments beyond the tile:
+    // the small deep maps fill only part of the 16 slots (10x10: 7, 12x12: 9, 14x14: 13), and dealt in blocks of four
+    // the live ones would all land on the first waves.
+    const int nfw = ((MT + 15) / 16 - wave + 3) / 4;        // live fragments of this wave (wave-uniform)
     int pbase[4], opix[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-        const int m = (wave * 4 + f) * 16 + r;
+        const int m = (f * 4 + wave) * 16 + r;
         int pr = 0, pc = 0;
         bool ok = m < MT;
         if (ok) { pr = fastdiv(m, a.CW, a.inv_cw); pc = m - pr * a.CW; }
@@ -143,32 +148,44 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     };
 
     const int nchunks = a.Cin / CK;
-    fetch(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        stash();
-        __syncthreads();
-        if (ch + 1 < nchunks) fetch(ch + 1);
-        // ---- MFMA over 9 taps x CK channels
+    // the channel-chunk loop, specialised on the number of live fragments (a run-time test per fragment inside the
+    // unrolled k-steps costs the full tiles 10 %: it cuts the MFMA / LDS-read schedule into small blocks)
+    auto chunks = [&](auto nf_tag) {
+        constexpr int NF = decltype(nf_tag)::value;
+        fetch(0);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            stash();
+            __syncthreads();
+            if (ch + 1 < nchunks) fetch(ch + 1);
+            // ---- MFMA over 9 taps x CK channels
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int k0 = s * KC + q * VEC;
-            int tap = k0 / CK;
-            const int c = k0 % CK;
-            tap = tap > 8 ? 8 : tap;  // padded k: weights are zero there, read any finite data
-            const int toff = ((tap / 3) * PW + (tap % 3)) * PXB + c * (int)sizeof(T);
-            uint4 fw[NBF], fp[4];
+            for (int s = 0; s < NS; ++s) {
+                const int k0 = s * KC + q * VEC;
+                int tap = k0 / CK;
+                const int c = k0 % CK;
+                tap = tap > 8 ? 8 : tap;  // padded k: weights are zero there, read any finite data
+                const int toff = ((tap / 3) * PW + (tap % 3)) * PXB + c * (int)sizeof(T);
+                uint4 fw[NBF], fp[NF > 0 ? NF : 1];
+                if (NF > 0) {
 #pragma unroll
-            for (int n = 0; n < NBF; ++n)
-                fw[n] = *reinterpret_cast<const uint4*>(wl + (n * 16 + r) * WROWB + k0 * (int)sizeof(T));
+                    for (int n = 0; n < NBF; ++n)
+                        fw[n] = *reinterpret_cast<const uint4*>(wl + (n * 16 + r) * WROWB + k0 * (int)sizeof(T));
+                }
 #pragma unroll
-            for (int f = 0; f < 4; ++f) fp[f] = *reinterpret_cast<const uint4*>(patch + pbase[f] + toff);
+                for (int f = 0; f < NF; ++f) fp[f] = *reinterpret_cast<const uint4*>(patch + pbase[f] + toff);
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+                for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int n = 0; n < NBF; ++n) Mma<T>::mma(acc[f][n], fw[n], fp[f]);
+                    for (int n = 0; n < NBF; ++n) Mma<T>::mma(acc[f][n], fw[n], fp[f]);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
+    };
+    if (nfw >= 4) chunks(std::integral_constant<int, 4>{});
+    else if (nfw == 3) chunks(std::integral_constant<int, 3>{});
+    else if (nfw == 2) chunks(std::integral_constant<int, 2>{});
+    else if (nfw == 1) chunks(std::integral_constant<int, 1>{});
+    else chunks(std::integral_constant<int, 0>{});
 
     // ---- epilogue.  After the MFMAs a lane owns 4 channels of one pixel per (fragment, channel block): stored as
     // they are, every store instruction scatters 8-byte pieces over 16 pixel rows (measured: the epilogue took 29 %

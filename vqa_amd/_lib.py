@@ -8,7 +8,8 @@ import os
 import torch
 
 _LIB = None
-_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libvqa_hip.so')
+# VQA_HIP_LIB: another build of the same library (same-box A/B runs of kernel variants)
+_PATH = os.environ.get('VQA_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libvqa_hip.so')
 
 F32, BF16, F16 = 0, 1, 2
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}

@@ -66,7 +66,9 @@ __device__ __forceinline__ int fastdiv(int i, int d, float inv) {
 // Sum over the 16 lanes that share lane>>4 (the lanes holding different D columns of the same rows).
 // DPP row operations (a DPP row = 16 lanes = exactly one lane>>4 group): 4 VALU ops, no LDS permute traffic.
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+    // mov_dpp (no "old" operand): the backend folds it into the consuming add as ONE v_add_f32_dpp; with
+    // update_dpp(0, ...) every step was v_mov + v_mov_dpp + v_add (the controls used here read only valid lanes)
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float sum16(float v) {
     v += dpp_mov<0x128>(v);   // row_ror:8
@@ -84,6 +86,68 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
     return v;
+}
+
+// ---- conv epilogue arithmetic on 4 accumulator values of one lane (4 consecutive channels of one pixel).
+// A wave64 VALU instruction costs its SIMD 4 cycles and the HBM-bound conv kernels are VALU-bound, so this is written
+// in packed f32x2 operations (v_pk_add/mul/fma_f32) with ONE bf16 conversion per pair, reused for the statistics and
+// for the store: per element 0.5 add (bias) + 0.5 cvt + 1 unpack + 0.5 mul (mask) + 0.5 add + 0.5 fma = 3.5 VALU,
+// against 6-7 for the scalar form (separate convert and back-convert, select, multiply, two adds).
+//   out   = round_T(acc + bias), optionally max(., 0)
+//   s1/s2 += okf * out, (okf * out)^2       (okf = 1 for a pixel inside the image, 0 otherwise)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct Packed4;
+template <> struct Packed4<bf16> { unsigned lo, hi; };        // channels 0-1, 2-3 as bf16 pairs
+template <> struct Packed4<float> { f32x2 lo, hi; };
+template <typename T, bool RELU, bool STATS = true>
+__device__ __forceinline__ Packed4<T> epilogue4(const f32x4& acc, const f32x4& bias, float okf, f32x2 (&s1)[2],
+                                                f32x2 (&s2)[2]) {
+    f32x2 p[2] = {f32x2{acc[0], acc[1]} + f32x2{bias[0], bias[1]}, f32x2{acc[2], acc[3]} + f32x2{bias[2], bias[3]}};
+    const f32x2 ok2 = {okf, okf};
+    Packed4<T> out;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (RELU) { p[h].x = fmaxf(p[h].x, 0.f); p[h].y = fmaxf(p[h].y, 0.f); }
+        f32x2 v;
+        if constexpr (sizeof(T) == 2) {
+            typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bf16x2_t t = {(bf16)p[h].x, (bf16)p[h].y};
+            const unsigned bits = __builtin_bit_cast(unsigned, t);
+            (h ? out.hi : out.lo) = bits;
+            if (STATS) v = f32x2{__uint_as_float(bits << 16), __uint_as_float(bits & 0xFFFF0000u)};   // what is stored
+        } else {
+            (h ? out.hi : out.lo) = p[h];
+            v = p[h];
+        }
+        if (STATS) {                                  // (the data gradient and the folded eval forward keep none)
+            const f32x2 m = v * ok2;
+            s1[h] += m;
+            s2[h] = __builtin_elementwise_fma(m, m, s2[h]);
+        }
+    }
+    return out;
+}
+template <typename T> __device__ __forceinline__ void store_packed4(T* p, const Packed4<T>& o);
+template <> __device__ __forceinline__ void store_packed4<bf16>(bf16* p, const Packed4<bf16>& o) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(o.lo, o.hi);
+}
+template <> __device__ __forceinline__ void store_packed4<float>(float* p, const Packed4<float>& o) {
+    *reinterpret_cast<float4*>(p) = make_float4(o.lo.x, o.lo.y, o.hi.x, o.hi.y);
+}
+// Sum of each of four values over the 16 lanes of a DPP row, every lane receiving the sums.  One v_add_f32_dpp per
+// step and value: written through the compiler's update_dpp builtin each step was v_mov + v_mov_dpp + v_add.  The
+// s_nop covers the VALU-write -> DPP-read hazard for the first row of adds (the assembler does not look inside an
+// asm block); within the block three other instructions separate a value's write from its next DPP read.
+__device__ __forceinline__ void sum16_x4(float& a, float& b, float& c, float& d) {
+#define VQA_DPP4(CTRL)                                                            \
+    "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n"              \
+    "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n"              \
+    "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n"              \
+    "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n"
+    asm("s_nop 1\n" VQA_DPP4("row_ror:8") VQA_DPP4("row_ror:4") VQA_DPP4("quad_perm:[2,3,0,1]")
+        VQA_DPP4("quad_perm:[1,0,3,2]")
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef VQA_DPP4
 }
 
 template <typename T> __device__ __forceinline__ void store_vec4(T* p, const float* v);

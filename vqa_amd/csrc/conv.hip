@@ -41,6 +41,11 @@ template <typename T, int CK> struct ConvCfg {
     static constexpr int KP = (9 * CK + KC - 1) / KC * KC;   // padded k per channel chunk
     static constexpr int NS = KP / KC;                       // chunks per channel chunk
     static constexpr int PXB = pix_stride(CK * (int)sizeof(T));   // LDS bytes per patch pixel
+    // Extra bytes per patch ROW.  A fragment of 16 consecutive tile pixels wraps to the next tile row whenever CW is not
+    // a multiple of 16 (every layer but the 16x16-tiled ones); the wrap must advance the LDS address like one more
+    // pixel step modulo the 256-byte bank period, or the fragment's ds_read_b128 costs 8 LDS cycles instead of 4
+    // (brute-forced over the hardware's lane groups for every tile shape in use): (PW - CW) * PXB + RPAD = 0 mod 256.
+    static constexpr int RPAD = (256 - (2 * PXB) % 256) % 256;
     static constexpr int WROWB = row_stride(KP * (int)sizeof(T)); // LDS bytes per weight row
     static constexpr int VPP = CK * (int)sizeof(T) / 16;     // 16-byte vectors per patch pixel
 };
@@ -55,9 +60,9 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
                   VPP = Cfg::VPP;
     constexpr int NB = NBF * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int PW = a.CW + 2, PPIX = (a.R + 2) * PW;
+    const int PW = a.CW + 2, PPIX = (a.R + 2) * PW, PROWB = PW * PXB + Cfg::RPAD;
     unsigned char* patch = smem;
-    unsigned char* wl = smem + (PPIX * PXB + 15) / 16 * 16;
+    unsigned char* wl = smem + (a.R + 2) * PROWB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
         bool ok = m < MT;
         if (ok) { pr = fastdiv(m, a.CW, a.inv_cw); pc = m - pr * a.CW; }
         ok = ok && (oy0 + pr < a.OH) && (ox0 + pc < a.OW);
-        pbase[f] = (pr * PW + pc) * PXB;
+        pbase[f] = pr * PROWB + pc * PXB;
         opix[f] = ok ? ((b * a.OH + oy0 + pr) * a.OW + ox0 + pc) : -1;
     }
 
@@ -107,6 +112,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     constexpr int NWV = (NB * WV + 255) / 256;
     const T* xb = x + (long)b * a.IH * a.IW * a.Cin;
     int psrc[NPV];                                              // element offset inside the image
+    int pdst[NPV];                                              // byte offset inside the LDS patch
     unsigned pmask[NPV];                                        // all-ones, or 0 = zero fill (AND, not a select: a
                                                                 // select lets hipcc branch around the load again)
 #pragma unroll
@@ -117,6 +123,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
         const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
         const bool ok = i < PPIX * VPP && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
         psrc[j] = ok ? (iy * a.IW + ix) * a.Cin + vv * VEC : 0;
+        pdst[j] = py * PROWB + pxx * PXB + vv * 16;
         pmask[j] = ok ? 0xFFFFFFFFu : 0u;
     }
     uint4 pv[NPV], wv[NWV];
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
         for (int j = 0; j < NPV; ++j) {
             const int i = tid + j * 256;
             const uint4 t = make_uint4(pv[j].x & pmask[j], pv[j].y & pmask[j], pv[j].z & pmask[j], pv[j].w & pmask[j]);
-            if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + (i / VPP) * PXB + (i % VPP) * 16) = t;
+            if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + pdst[j]) = t;
         }
 #pragma unroll
         for (int j = 0; j < NWV; ++j) {
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
                 int tap = k0 / CK;
                 const int c = k0 % CK;
                 tap = tap > 8 ? 8 : tap;  // padded k: weights are zero there, read any finite data
-                const int toff = ((tap / 3) * PW + (tap % 3)) * PXB + c * (int)sizeof(T);
+                const int toff = (tap / 3) * PROWB + (tap % 3) * PXB + c * (int)sizeof(T);
                 uint4 fw[NBF], fp[NF > 0 ? NF : 1];
                 if (NF > 0) {
 #pragma unroll
@@ -196,44 +203,47 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     constexpr int VPR = NB * (int)sizeof(T) / 16;           // 16-byte vectors per pixel row
     unsigned char* ew = smem + wave * 64 * EROW;
     int* epix = reinterpret_cast<int*>(smem + 4 * 64 * EROW) + wave * 64;
-    float s1[NBF][4], s2[NBF][4];
+    f32x2 s1[NBF][2], s2[NBF][2];
 #pragma unroll
     for (int n = 0; n < NBF; ++n)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s1[n][e] = s2[n][e] = 0.f;
+        for (int h = 0; h < 2; ++h) s1[n][h] = s2[n][h] = f32x2{0.f, 0.f};
+    auto finish = [&](auto mode_tag) {
+        constexpr bool RELU = (decltype(mode_tag)::value & 1) != 0, STATS = (decltype(mode_tag)::value & 2) != 0;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const bool ok = opix[f] >= 0;
-        if (q == 0) epix[f * 16 + r] = opix[f];
+        for (int f = 0; f < 4; ++f) {
+            const float okf = opix[f] >= 0 ? 1.f : 0.f;
+            if (q == 0) epix[f * 16 + r] = opix[f];
 #pragma unroll
-        for (int n = 0; n < NBF; ++n) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float pre = acc[f][n][e] + bv[n][e];
-                if (a.relu) pre = fmaxf(pre, 0.f);
-                v[e] = to_f32(from_f32<T>(pre));                       // statistics of what is stored
-                const float vs = ok ? v[e] : 0.f;
-                s1[n][e] += vs;
-                s2[n][e] += vs * vs;
+            for (int n = 0; n < NBF; ++n) {
+                const f32x4 bias4 = {bv[n][0], bv[n][1], bv[n][2], bv[n][3]};
+                const Packed4<T> o = epilogue4<T, RELU, STATS>(acc[f][n], bias4, okf, s1[n], s2[n]);
+                store_packed4<T>(reinterpret_cast<T*>(ew + (f * 16 + r) * EROW) + n * 16 + q * 4, o);
             }
-            store_vec4<T>(reinterpret_cast<T*>(ew + (f * 16 + r) * EROW) + n * 16 + q * 4, v);
         }
+    };
+    switch ((a.relu ? 1 : 0) | (a.stats ? 2 : 0)) {
+        case 0: finish(std::integral_constant<int, 0>{}); break;
+        case 1: finish(std::integral_constant<int, 1>{}); break;
+        case 2: finish(std::integral_constant<int, 2>{}); break;
+        default: finish(std::integral_constant<int, 3>{}); break;
     }
     if (a.stats) {
         // [4 waves][NB][2] behind the transpose regions: the sums are ready before any global store is issued, so the
         // barrier below does not wait for stores
         float* red = reinterpret_cast<float*>(smem + 4 * 64 * EROW + 4 * 64 * 4);
 #pragma unroll
-        for (int n = 0; n < NBF; ++n)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t1 = sum16(s1[n][e]), t2 = sum16(s2[n][e]);
-                if (r == 0) {
-                    red[(wave * NB + n * 16 + q * 4 + e) * 2 + 0] = t1;
-                    red[(wave * NB + n * 16 + q * 4 + e) * 2 + 1] = t2;
-                }
+        for (int n = 0; n < NBF; ++n) {
+            float t1[4] = {s1[n][0].x, s1[n][0].y, s1[n][1].x, s1[n][1].y};
+            float t2[4] = {s2[n][0].x, s2[n][0].y, s2[n][1].x, s2[n][1].y};
+            sum16_x4(t1[0], t1[1], t1[2], t1[3]);
+            sum16_x4(t2[0], t2[1], t2[2], t2[3]);
+            if (r == 0) {
+                float* dst = red + (wave * NB + n * 16 + q * 4) * 2;
+                *reinterpret_cast<float4*>(dst) = make_float4(t1[0], t2[0], t1[1], t2[1]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(t1[2], t2[2], t1[3], t2[3]);
             }
+        }
         __syncthreads();
         if (tid < NB * 2) {
             const float t = red[tid] + red[NB * 2 + tid] + red[2 * NB * 2 + tid] + red[3 * NB * 2 + tid];
@@ -265,9 +275,9 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
                   VPP = Cfg::VPP;
     constexpr int NB = NBF * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int PW = a.CW + 2, PPIX = (a.R + 2) * PW;
+    const int PW = a.CW + 2, PPIX = (a.R + 2) * PW, PROWB = PW * PXB + Cfg::RPAD;
     unsigned char* patch = smem;
-    unsigned char* wl = smem + (PPIX * PXB + 15) / 16 * 16;
+    unsigned char* wl = smem + (a.R + 2) * PROWB;
     float* biasl = reinterpret_cast<float*>(wl + NB * WROWB);   // [NB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -288,14 +298,14 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
         const int m = (wave * 4 + f) * 16 + r;
         int pr = 0, pc = 0;
         if (m < MT) { pr = fastdiv(m, a.CW, a.inv_cw); pc = m - pr * a.CW; }
-        pbase[f] = (pr * PW + pc) * PXB;
+        pbase[f] = pr * PROWB + pc * PXB;
         frc[f] = ((m < MT ? pr : 0x4000) << 16) | pc;
     }
     // ---- once per workgroup: coordinates of the patch vectors this thread stages, (py - pad) << 16 | (px - pad + 64)
     constexpr int PMAX = 384;                                   // host bound on (R+2)*(CW+2)
     constexpr int NPV = (PMAX * VPP + 255) / 256;
     constexpr int WV = KP / VEC;                                // vectors per weight row
-    int prel[NPV], pyx[NPV];
+    int prel[NPV], pyx[NPV], pdst[NPV];
 #pragma unroll
     for (int j = 0; j < NPV; ++j) {
         const int i = tid + j * 256;
@@ -303,6 +313,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
         const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
         pyx[j] = ((i < PPIX * VPP ? py - a.pad : -0x4000) << 16) | (pxx - a.pad + 64);
         prel[j] = ((py - a.pad) * a.IW + (pxx - a.pad)) * a.Cin + vv * VEC;
+        pdst[j] = py * PROWB + pxx * PXB + vv * 16;            // byte offset inside the LDS patch
     }
     // ---- once per workgroup: weight slab and bias into LDS
     {
@@ -314,11 +325,11 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
     }
 
     f32x4 acc[4][NBF];
-    float s1[NBF][4], s2[NBF][4];
+    f32x2 s1[NBF][2], s2[NBF][2];
 #pragma unroll
     for (int n = 0; n < NBF; ++n)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s1[n][e] = s2[n][e] = 0.f;
+        for (int h = 0; h < 2; ++h) s1[n][h] = s2[n][h] = f32x2{0.f, 0.f};
 
     // ---- staging.  Loads are branch-free (out-of-image lanes read the image's first bytes and are zeroed by an AND
     // in stash(): a select lets hipcc branch around each load and serialise them); the next tile's loads are issued
@@ -348,7 +359,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
             const int i = tid + j * 256;
             const unsigned m = (unsigned)(-(int)((okbits >> j) & 1u));
             const uint4 t = make_uint4(pv[j].x & m, pv[j].y & m, pv[j].z & m, pv[j].w & m);
-            if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + (i / VPP) * PXB + (i % VPP) * 16) = t;
+            if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + pdst[j]) = t;
         }
     };
 
@@ -369,7 +380,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
             int tap = k0 / CK;
             const int c = k0 % CK;
             tap = tap > 8 ? 8 : tap;  // padded k: weights are zero there, read any finite data
-            const int toff = ((tap / 3) * PW + (tap % 3)) * PXB + c * (int)sizeof(T);
+            const int toff = (tap / 3) * PROWB + (tap % 3) * PXB + c * (int)sizeof(T);
             uint4 fw[NBF], fp[4];
 #pragma unroll
             for (int n = 0; n < NBF; ++n)
@@ -383,25 +394,25 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
         }
         // ---- epilogue: + bias, store (lane owns 4 consecutive channels of one pixel), BN partial statistics
         T* yt = y + ((long)(cb * a.OH + coy0) * a.OW + cox0) * a.Cout + co0 + q * 4;
+        auto finish = [&](auto mode_tag) {
+            constexpr bool RELU = (decltype(mode_tag)::value & 1) != 0, STATS = (decltype(mode_tag)::value & 2) != 0;
 #pragma unroll
-        for (int n = 0; n < NBF; ++n) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(biasl + n * 16 + q * 4);
+            for (int n = 0; n < NBF; ++n) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(biasl + n * 16 + q * 4);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const int pr = frc[f] >> 16, pc = frc[f] & 0xFFFF;
-                const bool ok = coy0 + pr < a.OH && cox0 + pc < a.OW;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float pre = acc[f][n][e] + bv[e];
-                    if (a.relu) pre = fmaxf(pre, 0.f);
-                    v[e] = to_f32(from_f32<T>(pre));                   // statistics of what is stored
-                    const float vs = ok ? v[e] : 0.f;
-                    s1[n][e] += vs;
-                    s2[n][e] += vs * vs;
+                for (int f = 0; f < 4; ++f) {
+                    const int pr = frc[f] >> 16, pc = frc[f] & 0xFFFF;
+                    const bool ok = coy0 + pr < a.OH && cox0 + pc < a.OW;
+                    const Packed4<T> o = epilogue4<T, RELU, STATS>(acc[f][n], bv, ok ? 1.f : 0.f, s1[n], s2[n]);
+                    if (ok) store_packed4<T>(yt + (pr * a.OW + pc) * a.Cout + n * 16, o);
                 }
-                if (ok) store_vec4<T>(yt + (pr * a.OW + pc) * a.Cout + n * 16, v);
             }
+        };
+        switch ((a.relu ? 1 : 0) | (a.stats ? 2 : 0)) {
+            case 0: finish(std::integral_constant<int, 0>{}); break;
+            case 1: finish(std::integral_constant<int, 1>{}); break;
+            case 2: finish(std::integral_constant<int, 2>{}); break;
+            default: finish(std::integral_constant<int, 3>{}); break;
         }
         __syncthreads();
     }
@@ -409,15 +420,17 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
     if (a.stats) {
         float* red = reinterpret_cast<float*>(smem);  // [4 waves][NB][2]; staging LDS is free after the last sync
 #pragma unroll
-        for (int n = 0; n < NBF; ++n)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t1 = sum16(s1[n][e]), t2 = sum16(s2[n][e]);
-                if (r == 0) {
-                    red[(wave * NB + n * 16 + q * 4 + e) * 2 + 0] = t1;
-                    red[(wave * NB + n * 16 + q * 4 + e) * 2 + 1] = t2;
-                }
+        for (int n = 0; n < NBF; ++n) {
+            float t1[4] = {s1[n][0].x, s1[n][0].y, s1[n][1].x, s1[n][1].y};
+            float t2[4] = {s2[n][0].x, s2[n][0].y, s2[n][1].x, s2[n][1].y};
+            sum16_x4(t1[0], t1[1], t1[2], t1[3]);
+            sum16_x4(t2[0], t2[1], t2[2], t2[3]);
+            if (r == 0) {
+                float* dst = red + (wave * NB + n * 16 + q * 4) * 2;
+                *reinterpret_cast<float4*>(dst) = make_float4(t1[0], t2[0], t1[1], t2[1]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(t1[2], t2[2], t1[3], t2[3]);
             }
+        }
         __syncthreads();
         if (tid < NB * 2) {
             const float tt = red[tid] + red[NB * 2 + tid] + red[2 * NB * 2 + tid] + red[3 * NB * 2 + tid];
@@ -430,8 +443,8 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
 template <typename T, int CK, int NBF>
 size_t igemm_lds(const ConvArgs& a) {
     using Cfg = ConvCfg<T, CK>;
-    const int PPIX = (a.R + 2) * (a.CW + 2);
-    size_t lds = (size_t)(PPIX * Cfg::PXB + 15) / 16 * 16 + (size_t)NBF * 16 * Cfg::WROWB + (size_t)NBF * 16 * 4;
+    size_t lds = (size_t)(a.R + 2) * ((a.CW + 2) * Cfg::PXB + Cfg::RPAD) + (size_t)NBF * 16 * Cfg::WROWB +
+                 (size_t)NBF * 16 * 4;
     if (lds < (size_t)4 * NBF * 16 * 2 * sizeof(float)) lds = (size_t)4 * NBF * 16 * 2 * sizeof(float);
     const size_t epi = (size_t)4 * 64 * (NBF * 16 * sizeof(T) + 16) + 4 * 64 * 4 +   // tile kernel's store transpose
                        (size_t)4 * NBF * 16 * 2 * 4;                                   // + its statistics rows

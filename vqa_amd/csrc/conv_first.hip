@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
         pbase[f] = (pr * PW + pc) * 2;
         frc[f] = ((m < MT ? pr : 0x4000) << 16) | pc;
     }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 s1[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, s2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+    const f32x4 bias4 = {bv[0], bv[1], bv[2], bv[3]};
 
     float pv[NIV];
     unsigned okbits;
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
         ox0 = (tl - ty * a.tiles_x) * a.CW;
     };
     int fb, foy0, fox0;
+    const bool relu = a.relu != 0;
     tile_org(blockIdx.x, fb, foy0, fox0);
     fetch_patch<TI>(a, img, pl, fb, foy0, fox0, pv, okbits);
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
@@ -161,17 +163,10 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) fp[j] = *reinterpret_cast<const bf16*>(base + koff[j]);
                 f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fp, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float pre = acc[e] + bv[e];
-                    if (a.relu) pre = fmaxf(pre, 0.f);
-                    o[e] = (bf16)pre;
-                    const float v = ok ? (float)o[e] : 0.f;          // statistics of what is stored
-                    s1[e] += v;
-                    s2[e] += v * v;
-                }
-                pk[h] = __builtin_bit_cast(uint2, o);
+                const float okf = ok ? 1.f : 0.f;
+                const Packed4<bf16> o = relu ? epilogue4<bf16, true>(acc, bias4, okf, s1, s2)
+                                             : epilogue4<bf16, false>(acc, bias4, okf, s1, s2);
+                pk[h] = make_uint2(o.lo, o.hi);
             }
             auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
             auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
@@ -183,12 +178,14 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
     }
     if (a.stats) {                                            // one row of partial sums per workgroup
         float* red = reinterpret_cast<float*>(smem);          // [4 waves][16][2]
+        float t1[4] = {s1[0].x, s1[0].y, s1[1].x, s1[1].y}, t2[4] = {s2[0].x, s2[0].y, s2[1].x, s2[1].y};
+        sum16_x4(t1[0], t1[1], t1[2], t1[3]);
+        sum16_x4(t2[0], t2[1], t2[2], t2[3]);
+        if (r == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float t1 = sum16(s1[e]), t2 = sum16(s2[e]);
-            if (r == 0) {
-                red[(wave * 16 + q * 4 + e) * 2 + 0] = t1;
-                red[(wave * 16 + q * 4 + e) * 2 + 1] = t2;
+            for (int e = 0; e < 4; ++e) {
+                red[(wave * 16 + q * 4 + e) * 2 + 0] = t1[e];
+                red[(wave * 16 + q * 4 + e) * 2 + 1] = t2[e];
             }
         }
         __syncthreads();

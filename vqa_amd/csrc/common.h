@@ -134,6 +134,35 @@ template <> __device__ __forceinline__ void store_packed4<bf16>(bf16* p, const P
 template <> __device__ __forceinline__ void store_packed4<float>(float* p, const Packed4<float>& o) {
     *reinterpret_cast<float4*>(p) = make_float4(o.lo.x, o.lo.y, o.hi.x, o.hi.y);
 }
+// ---- buffer-resource addressing.  A raw buffer access whose byte offset is >= the buffer's size is dropped by the
+// hardware: a load returns zeros, a store writes nothing.  The conv kernels use that for the zero padding and for
+// the tile overhang: an out-of-image element gets the offset `size` (one select) instead of a clamped address, an AND
+// mask over the loaded data at the LDS write and a branch around the store - and straight-line code is also what lets
+// the compiler count its s_waitcnt vmcnt exactly (behind a branch that may skip the stores it waits for them too).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buffer_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void buffer_store16(__amdgpu_buffer_rsrc_t r, unsigned off, const uint4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, r, off, 0, 0);
+}
+template <typename T> __device__ __forceinline__ void buffer_store_packed4(__amdgpu_buffer_rsrc_t r, unsigned off,
+                                                                           const Packed4<T>& o);
+template <> __device__ __forceinline__ void buffer_store_packed4<bf16>(__amdgpu_buffer_rsrc_t r, unsigned off,
+                                                                       const Packed4<bf16>& o) {
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{o.lo, o.hi}, r, off, 0, 0);
+}
+template <> __device__ __forceinline__ void buffer_store_packed4<float>(__amdgpu_buffer_rsrc_t r, unsigned off,
+                                                                        const Packed4<float>& o) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(o.lo.x), __float_as_uint(o.lo.y),
+                                                 __float_as_uint(o.hi.x), __float_as_uint(o.hi.y)}, r, off, 0, 0);
+}
+
 // Sum of each of four values over the 16 lanes of a DPP row, every lane receiving the sums.  One v_add_f32_dpp per
 // step and value: written through the compiler's update_dpp builtin each step was v_mov + v_mov_dpp + v_add.  The
 // s_nop covers the VALU-write -> DPP-read hazard for the first row of adds (the assembler does not look inside an

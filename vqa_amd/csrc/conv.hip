@@ -285,9 +285,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
     const int co0 = blockIdx.y * NB;
     const int MT = a.R * a.CW;
     const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
-    const T* x = static_cast<const T*>(a.x);
     const T* w = static_cast<const T*>(a.w);
-    T* y = static_cast<T*>(a.y);
     if ((int)blockIdx.x >= total) return;                       // (host launches G <= total)
 
     // ---- once per workgroup: fragment pixel decode (4 fragments of 16 consecutive tile pixels per wave);
@@ -312,9 +310,12 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
         const int px = i / VPP, vv = i % VPP;
         const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
         pyx[j] = ((i < PPIX * VPP ? py - a.pad : -0x4000) << 16) | (pxx - a.pad + 64);
-        prel[j] = ((py - a.pad) * a.IW + (pxx - a.pad)) * a.Cin + vv * VEC;
+        prel[j] = (((py - a.pad) * a.IW + (pxx - a.pad)) * a.Cin + vv * VEC) * (int)sizeof(T);   // bytes from the tile origin
         pdst[j] = py * PROWB + pxx * PXB + vv * 16;            // byte offset inside the LDS patch
     }
+    const unsigned xbytes = (unsigned)a.B * a.IH * a.IW * a.Cin * (unsigned)sizeof(T);   // (host: both < 2^32)
+    const unsigned ybytes = (unsigned)a.B * a.OH * a.OW * a.Cout * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xbuf = buffer_of(a.x, xbytes), ybuf = buffer_of(a.y, ybytes);
     // ---- once per workgroup: weight slab and bias into LDS
     {
         const T* wsrc = w + (long)co0 * KP;
@@ -331,34 +332,30 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) s1[n][h] = s2[n][h] = f32x2{0.f, 0.f};
 
-    // ---- staging.  Loads are branch-free (out-of-image lanes read the image's first bytes and are zeroed by an AND
-    // in stash(): a select lets hipcc branch around each load and serialise them); the next tile's loads are issued
-    // before the MFMA phase of this one and written to LDS after it (register prefetch, single LDS buffer).
+    // ---- staging.  Out-of-image vectors are fetched at the buffer's size, which the hardware answers with zeros (the
+    // zero padding costs one select per vector: no clamped address, no mask at the LDS write, no branch); the next
+    // tile's loads are issued before the MFMA phase of this one and written to LDS after it (register prefetch,
+    // single LDS buffer).
     uint4 pv[NPV];
-    unsigned okbits = 0;                                        // bit j: vector j of the fetched tile is inside the image
     int fb = 0, foy0 = 0, fox0 = 0;                             // image / output origin of the fetched tile
     auto fetch = [&](int t) {
         const int b = fastdiv(t, tiles, a.inv_tiles), tl = t - b * tiles;
         const int ty = fastdiv(tl, a.tiles_x, a.inv_tx), tx = tl - ty * a.tiles_x;
         const int oy0 = ty * a.R, ox0 = tx * a.CW;
         fb = b; foy0 = oy0; fox0 = ox0;
-        const int org = (oy0 * a.IW + ox0) * a.Cin;
-        const T* xt = x + (long)b * a.IH * a.IW * a.Cin + org;  // top-left input pixel of the tile
-        okbits = 0;
+        const unsigned org = (unsigned)((b * a.IH + oy0) * a.IW + ox0) * a.Cin * (unsigned)sizeof(T);
 #pragma unroll
         for (int j = 0; j < NPV; ++j) {
             const bool ok = (unsigned)(oy0 + (pyx[j] >> 16)) < (unsigned)a.IH &&
                             (unsigned)(ox0 - 64 + (pyx[j] & 0xFFFF)) < (unsigned)a.IW;
-            okbits |= ok ? (1u << j) : 0u;
-            pv[j] = *reinterpret_cast<const uint4*>(xt + (ok ? prel[j] : -org));
+            pv[j] = buffer_load16(xbuf, ok ? org + (unsigned)prel[j] : xbytes);
         }
     };
     auto stash = [&]() {
 #pragma unroll
         for (int j = 0; j < NPV; ++j) {
             const int i = tid + j * 256;
-            const unsigned m = (unsigned)(-(int)((okbits >> j) & 1u));
-            const uint4 t = make_uint4(pv[j].x & m, pv[j].y & m, pv[j].z & m, pv[j].w & m);
+            const uint4 t = pv[j];   // by value first: a conditional store straight from the array keeps it in scratch
             if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + pdst[j]) = t;
         }
     };
@@ -393,7 +390,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
                 for (int n = 0; n < NBF; ++n) Mma<T>::mma(acc[f][n], fw[n], fp[f]);
         }
         // ---- epilogue: + bias, store (lane owns 4 consecutive channels of one pixel), BN partial statistics
-        T* yt = y + ((long)(cb * a.OH + coy0) * a.OW + cox0) * a.Cout + co0 + q * 4;
+        const unsigned yt = ((unsigned)((cb * a.OH + coy0) * a.OW + cox0) * a.Cout + co0 + q * 4) * (unsigned)sizeof(T);
         auto finish = [&](auto mode_tag) {
             constexpr bool RELU = (decltype(mode_tag)::value & 1) != 0, STATS = (decltype(mode_tag)::value & 2) != 0;
 #pragma unroll
@@ -404,7 +401,8 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
                     const int pr = frc[f] >> 16, pc = frc[f] & 0xFFFF;
                     const bool ok = coy0 + pr < a.OH && cox0 + pc < a.OW;
                     const Packed4<T> o = epilogue4<T, RELU, STATS>(acc[f][n], bv, ok ? 1.f : 0.f, s1[n], s2[n]);
-                    if (ok) store_packed4<T>(yt + (pr * a.OW + pc) * a.Cout + n * 16, o);
+                    buffer_store_packed4<T>(
+                        ybuf, ok ? yt + (unsigned)((pr * a.OW + pc) * a.Cout + n * 16) * (unsigned)sizeof(T) : ybytes, o);
                 }
             }
         };
@@ -860,6 +858,9 @@ static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* w
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || R * CW > 256 ||
         (R + 2) * (CW + 2) > 384 || B < 1)
         return bad;
+    // the kernels address x and y through 32-bit byte offsets (buffer resources)
+    const int esz_ = dtype == VQA_BF16 ? 2 : 4;
+    if ((double)B * IH * IW * Cin * esz_ >= 4294967040.0 || (double)B * OH * OW * Cout * esz_ >= 4294967040.0) return bad;
     const int tx_ = (OW + CW - 1) / CW, ty_ = (OH + R - 1) / R;
     ConvArgs a{x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
                1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), relu};

@@ -273,17 +273,48 @@ __global__ void gru_gate_bwd(const float* dh, const float* save, const float* hp
 
 // ---------------------------------------------------------------------------------------- attention
 // One workgroup (256 threads) per batch element: s_k = a[b,k,:].w_s ; p = softmax_k(s) ; vhat = sum_k p_k v[b,k,:]
+// Every access to `a` is a 16-byte vector per lane (H % (16 / sizeof(T)) == 0, D % 4 == 0: checked by the entry):
+// with 2-byte lane accesses these two kernels took 40 + 44 us for 13 MB.
+template <typename T> struct Vec16 {
+    static constexpr int N = 16 / sizeof(T);
+    static __device__ __forceinline__ void load(const T* p, float* f) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int i = 0; i < N; ++i) f[i] = to_f32(e[i]);
+    }
+    static __device__ __forceinline__ void store(T* p, const float* f) {
+        T e[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) e[i] = from_f32<T>(f[i]);
+        *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(e);
+    }
+};
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd(const T* a, const T* ws, const float* v, int K, int H, int D, float* p,
-                                                float* vhat, T* vhat_t) {
-    extern __shared__ float sm[];  // s[K]
+__global__ __launch_bounds__(256) void attn_fwd(const T* __restrict__ a, const T* __restrict__ ws,
+                                                const float* __restrict__ v, int K, int H, int D, float* p, float* vhat,
+                                                T* vhat_t) {
+    constexpr int N = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // s[K], then the weighted-sum combine
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = wave; k < K; k += 4) {
-        const T* row = a + ((long)b * K + k) * H;
-        float s = 0.f;
-        for (int j = lane; j < H; j += 64) s += to_f32(row[j]) * to_f32(ws[j]);
-        s = wave_sum(s);
-        if (lane == 0) sm[k] = s;
+    const int HV = H / N;
+    // scores: wave w takes rows w, w+4, ..., two rows per round so that four or more loads are in flight per lane
+    for (int k = wave; k < K; k += 8) {
+        const bool two = k + 4 < K;
+        const T* row0 = a + ((long)b * K + k) * H;
+        const T* row1 = a + ((long)b * K + (two ? k + 4 : k)) * H;
+        float s0 = 0.f, s1 = 0.f;
+        for (int jv = lane; jv < HV; jv += 64) {
+            float x0[N], x1[N], w[N];
+            Vec16<T>::load(row0 + jv * N, x0);
+            Vec16<T>::load(row1 + jv * N, x1);
+            Vec16<T>::load(ws + jv * N, w);
+#pragma unroll
+            for (int e = 0; e < N; ++e) { s0 += x0[e] * w[e]; s1 += x1[e] * w[e]; }
+        }
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        if (lane == 0) { sm[k] = s0; if (two) sm[k + 4] = s1; }
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -291,25 +322,54 @@ __global__ __launch_bounds__(256) void attn_fwd(const T* a, const T* ws, const f
     float den = 0.f;
     for (int k = 0; k < K; ++k) den += __expf(sm[k] - mx);
     const float inv = 1.f / den;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float acc = 0.f;
-        for (int k = 0; k < K; ++k) acc += __expf(sm[k] - mx) * inv * v[((long)b * K + k) * D + d];
-        vhat[(long)b * D + d] = acc;
-        vhat_t[(long)b * D + d] = from_f32<T>(acc);
+    // weighted sum: thread = (4-channel vector dv, row residue kr): K rows split over 256 / (D/4) residues, then
+    // combined through LDS in a fixed order
+    const int DV = D / 4, nres = 256 / DV > 0 ? 256 / DV : 1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int dv = threadIdx.x % DV, kr = threadIdx.x / DV;
+    if (kr < nres) {
+        for (int k = kr; k < K; k += nres) {
+            const float pk = __expf(sm[k] - mx) * inv;
+            const float4 x = *reinterpret_cast<const float4*>(v + ((long)b * K + k) * D + dv * 4);
+            acc.x += pk * x.x; acc.y += pk * x.y; acc.z += pk * x.z; acc.w += pk * x.w;
+        }
     }
     for (int k = threadIdx.x; k < K; k += blockDim.x) p[(long)b * K + k] = __expf(sm[k] - mx) * inv;
+    __syncthreads();                                            // sm[] is reused for the combine
+    float4* part = reinterpret_cast<float4*>(sm);               // [nres][DV]   (entry sizes LDS for it)
+    if (kr < nres) part[kr * DV + dv] = acc;
+    __syncthreads();
+    if (threadIdx.x < DV) {
+        float4 t = part[threadIdx.x];
+        for (int i = 1; i < nres; ++i) {
+            const float4 u = part[i * DV + threadIdx.x];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        *reinterpret_cast<float4*>(vhat + (long)b * D + threadIdx.x * 4) = t;
+        const float o[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vhat_t[(long)b * D + threadIdx.x * 4 + e] = from_f32<T>(o[e]);
+    }
 }
 // dp_k = v[b,k,:].dvhat[b];  ds_k = p_k (dp_k - sum_j p_j dp_j);  dv[b,k,:] = p_k dvhat[b];
 // dpre[b,k,:] = ds_k * w_s * 1[a>0];  dws_part[b][:] = sum_k ds_k a[b,k,:]
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd(const T* a, const T* ws, const float* v, const float* p,
-                                                const float* dvhat, int K, int H, int D, float* dv, T* dpre,
-                                                float* dws_part) {
-    extern __shared__ float sm[];  // ds[K]
+__global__ __launch_bounds__(256) void attn_bwd(const T* __restrict__ a, const T* __restrict__ ws,
+                                                const float* __restrict__ v, const float* __restrict__ p,
+                                                const float* __restrict__ dvhat, int K, int H, int D,
+                                                float* __restrict__ dv, T* __restrict__ dpre,
+                                                float* __restrict__ dws_part) {
+    constexpr int N = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // ds[K], then the dws combine
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int DV = D / 4;
     for (int k = wave; k < K; k += 4) {
         float s = 0.f;
-        for (int d = lane; d < D; d += 64) s += v[((long)b * K + k) * D + d] * dvhat[(long)b * D + d];
+        for (int d4 = lane; d4 < DV; d4 += 64) {
+            const float4 x = *reinterpret_cast<const float4*>(v + ((long)b * K + k) * D + d4 * 4);
+            const float4 g = *reinterpret_cast<const float4*>(dvhat + (long)b * D + d4 * 4);
+            s += x.x * g.x + x.y * g.y + x.z * g.z + x.w * g.w;
+        }
         s = wave_sum(s);
         if (lane == 0) sm[k] = s;
     }
@@ -319,19 +379,46 @@ __global__ __launch_bounds__(256) void attn_bwd(const T* a, const T* ws, const f
     __syncthreads();
     for (int k = threadIdx.x; k < K; k += blockDim.x) sm[k] = p[(long)b * K + k] * (sm[k] - dot);
     __syncthreads();
-    for (int k = 0; k < K; ++k) {
+    // dv rows: one float4 per thread and step
+    for (int i = threadIdx.x; i < K * DV; i += blockDim.x) {
+        const int k = i / DV, d4 = i - k * DV;
         const float pk = p[(long)b * K + k];
-        for (int d = threadIdx.x; d < D; d += blockDim.x) dv[((long)b * K + k) * D + d] = pk * dvhat[(long)b * D + d];
+        const float4 g = *reinterpret_cast<const float4*>(dvhat + (long)b * D + d4 * 4);
+        *reinterpret_cast<float4*>(dv + ((long)b * K + k) * D + d4 * 4) = make_float4(pk * g.x, pk * g.y, pk * g.z, pk * g.w);
     }
-    for (int j = threadIdx.x; j < H; j += blockDim.x) {
-        const float w = to_f32(ws[j]);
-        float acc = 0.f;
-        for (int k = 0; k < K; ++k) {
-            const float av = to_f32(a[((long)b * K + k) * H + j]);
-            acc += sm[k] * av;
-            dpre[((long)b * K + k) * H + j] = from_f32<T>(av > 0.f ? sm[k] * w : 0.f);
+    // dpre / dws: thread = (16-byte channel vector jv, row residue kr); each 16-byte vector of `a` is read once
+    const int HV = H / N;
+    float* comb = sm + ((K + 3) / 4) * 4;                       // [nres][H] partial dws (entry sizes LDS for it)
+    for (int j0 = 0; j0 < HV; j0 += 256) {                      // (one round for H <= 256 * N)
+        const int span = HV - j0 < 256 ? HV - j0 : 256;         // vectors handled in this round
+        const int nres = 256 / span > 0 ? 256 / span : 1;
+        const int jl = threadIdx.x % span, kr = threadIdx.x / span, jv = j0 + jl;
+        float acc[N], w[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[e] = 0.f;
+        if (kr < nres) {
+            Vec16<T>::load(ws + jv * N, w);
+            for (int k = kr; k < K; k += nres) {
+                float av[N], o[N];
+                Vec16<T>::load(a + ((long)b * K + k) * H + jv * N, av);
+                const float dsk = sm[k];
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    acc[e] += dsk * av[e];
+                    o[e] = av[e] > 0.f ? dsk * w[e] : 0.f;
+                }
+                Vec16<T>::store(dpre + ((long)b * K + k) * H + jv * N, o);
+            }
+#pragma unroll
+            for (int e = 0; e < N; ++e) comb[(kr * span + jl) * N + e] = acc[e];
         }
-        dws_part[(long)b * H + j] = acc;
+        __syncthreads();
+        for (int i = threadIdx.x; i < span * N; i += blockDim.x) {
+            float t = comb[i];
+            for (int r2 = 1; r2 < nres; ++r2) t += comb[r2 * span * N + i];
+            dws_part[(long)b * H + j0 * N + i] = t;
+        }
+        __syncthreads();
     }
 }
 // out[b][:] = sum_k x[b*K + k][:]
@@ -635,7 +722,11 @@ extern "C" int vqa_gru_gate_bwd(void* stream, int dtype, const float* dh, const 
 
 extern "C" int vqa_attn_fwd(void* stream, int dtype, const void* a, const void* ws, const float* v, int B, int K,
                             int H, int D, float* p, float* vhat, void* vhat_t) {
-    const size_t lds = (size_t)K * sizeof(float);
+    const int N = dtype == VQA_BF16 ? 8 : 4;
+    if (K < 1 || H % N || D % 4 || D / 4 > 256) return VQA_ERR_ARG;
+    const int nres = 256 / (D / 4);
+    size_t lds = (size_t)K * sizeof(float);
+    if (lds < (size_t)nres * D * sizeof(float)) lds = (size_t)nres * D * sizeof(float);
     BY_T(dtype, hipLaunchKernelGGL(attn_fwd<bf16>, dim3(B), dim3(256), lds, ST, (const bf16*)a, (const bf16*)ws, v, K, H, D, p, vhat, (bf16*)vhat_t),
          hipLaunchKernelGGL(attn_fwd<float>, dim3(B), dim3(256), lds, ST, (const float*)a, (const float*)ws, v, K, H, D, p, vhat, (float*)vhat_t));
     CHECK_LAUNCH();
@@ -644,7 +735,10 @@ extern "C" int vqa_attn_fwd(void* stream, int dtype, const void* a, const void* 
 
 extern "C" int vqa_attn_bwd(void* stream, int dtype, const void* a, const void* ws, const float* v, const float* p,
                             const float* dvhat, int B, int K, int H, int D, float* dv, void* dpre, float* dws_part) {
-    const size_t lds = (size_t)K * sizeof(float);
+    const int N = dtype == VQA_BF16 ? 8 : 4;
+    if (K < 1 || H % N || D % 4) return VQA_ERR_ARG;
+    // ds[K] + the dws combine: per round min(H/N, 256) vectors x (256 / that) row residues x N floats <= 256 * N floats
+    const size_t lds = ((size_t)(K + 3) / 4 * 4 + (size_t)256 * N) * sizeof(float);
     BY_T(dtype, hipLaunchKernelGGL(attn_bwd<bf16>, dim3(B), dim3(256), lds, ST, (const bf16*)a, (const bf16*)ws, v, p, dvhat, K, H, D, dv, (bf16*)dpre, dws_part),
          hipLaunchKernelGGL(attn_bwd<float>, dim3(B), dim3(256), lds, ST, (const float*)a, (const float*)ws, v, p, dvhat, K, H, D, dv, (float*)dpre, dws_part));
     CHECK_LAUNCH();

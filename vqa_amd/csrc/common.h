@@ -88,6 +88,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// four consecutive values per thread: float4 in, 8- or 16-byte out
+template <typename T> __device__ __forceinline__ void store4(T* p, const float* v);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float* v) {
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+__device__ __forceinline__ void load4(const float* p, float* v) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+
 // ---- conv epilogue arithmetic on 4 accumulator values of one lane (4 consecutive channels of one pixel).
 // A wave64 VALU instruction costs its SIMD 4 cycles and the HBM-bound conv kernels are VALU-bound, so this is written
 // in packed f32x2 operations (v_pk_add/mul/fma_f32) with ONE bf16 conversion per pair, reused for the statistics and

@@ -314,22 +314,51 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
     }
 }
 
-// C = epilogue(sum_z ws[z]) in fixed slice order
-template <typename TC>
+// C = epilogue(sum_z ws[z]) in fixed slice order.  VEC4: four consecutive columns per thread (N, ldc, ldc2 multiples
+// of 4: the launcher checks), one element otherwise.
+template <typename TC, bool VEC4>
 __global__ void gemm_splitk_reduce(GemmArgs g, int splits) {
+    constexpr int V = VEC4 ? 4 : 1;
     TC* C = static_cast<TC*>(g.C);
     const long total = (long)g.M * g.N;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int n = i % g.N;
-        const long m = i / g.N;
-        float x = 0.f;
-        for (int z = 0; z < splits; ++z) x += g.ws[(long)z * total + i];
-        if (g.bias) x += g.bias[n];
-        if (g.rowadd) x += g.rowadd[(m / g.rowadd_group) * g.N + n];
-        if (g.act == 1) x = fmaxf(x, 0.f);
-        if (g.accumulate) x += to_f32(C[m * g.ldc + n]);
-        C[m * g.ldc + n] = from_f32<TC>(x);
-        if (g.C2) g.C2[m * g.ldc2 + n] = (bf16)x;
+    const int nv = g.N / V;
+    for (long iv = (long)blockIdx.x * blockDim.x + threadIdx.x; iv < total / V; iv += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(iv % nv) * V;
+        const long m = iv / nv;
+        const long i = m * g.N + n;
+        float x[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) x[e] = 0.f;
+        for (int z = 0; z < splits; ++z) {
+            if constexpr (VEC4) {
+                const float4 t = *reinterpret_cast<const float4*>(g.ws + (long)z * total + i);
+                x[0] += t.x; x[1] += t.y; x[2] += t.z; x[3] += t.w;
+            } else {
+                x[0] += g.ws[(long)z * total + i];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            if (g.bias) x[e] += g.bias[n + e];
+            if (g.rowadd) x[e] += g.rowadd[(m / g.rowadd_group) * g.N + n + e];
+            if (g.act == 1) x[e] = fmaxf(x[e], 0.f);
+            if (g.accumulate) x[e] += to_f32(C[m * g.ldc + n + e]);
+        }
+        if constexpr (VEC4) {
+            if constexpr (sizeof(TC) == 4) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + m * g.ldc + n) = make_float4(x[0], x[1], x[2], x[3]);
+            } else {
+                bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(C) + m * g.ldc + n) = o;
+            }
+            if (g.C2) {
+                bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
+                *reinterpret_cast<bf16x4*>(g.C2 + m * g.ldc2 + n) = o;
+            }
+        } else {
+            C[m * g.ldc + n] = from_f32<TC>(x[0]);
+            if (g.C2) g.C2[m * g.ldc2 + n] = (bf16)x[0];
+        }
     }
 }
 
@@ -366,9 +395,12 @@ int launch(hipStream_t s, int trans, const GemmArgs& g, int splits) {
         else hipLaunchKernelGGL((gemm_kernel<T, TC, false>), grid, dim3(256), 0, s, g);
     }
     if (g.ws) {
-        long blocks = ((long)g.M * g.N + 255) / 256;
-        hipLaunchKernelGGL(gemm_splitk_reduce<TC>, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, g,
-                           splits);
+        const bool v4 = g.N % 4 == 0 && g.ldc % 4 == 0 && (!g.C2 || g.ldc2 % 4 == 0) &&
+                        (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.C2) & 7) == 0 &&
+                        (reinterpret_cast<uintptr_t>(g.ws) & 15) == 0;
+        const long blocks = ((long)g.M * g.N / (v4 ? 4 : 1) + 255) / 256;      // one item per thread
+        if (v4) hipLaunchKernelGGL((gemm_splitk_reduce<TC, true>), dim3((unsigned)blocks), dim3(256), 0, s, g, splits);
+        else hipLaunchKernelGGL((gemm_splitk_reduce<TC, false>), dim3((unsigned)blocks), dim3(256), 0, s, g, splits);
     }
     CHECK_LAUNCH();
     return VQA_OK;

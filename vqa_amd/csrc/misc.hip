@@ -198,14 +198,31 @@ __global__ __launch_bounds__(256) void wn_bwd_all(WnJobs j) {
     if (blockIdx.x == 0 && threadIdx.x == 0) j.dg[job][0] = dot / nrm;
 }
 
-// cast / pad: dst[m][0..ldd) = src[m][0..N) then zeros
-template <typename TS, typename TD>
-__global__ void cast_pad(const TS* src, int M, int N, int lds, TD* dst, int ldd) {
-    const long total = (long)M * ldd;
+// cast / pad: dst[m][0..ldd) = src[m][0..N) then zeros.  VEC4: four consecutive elements per thread (N, lds, ldd
+// multiples of 4 and 16-byte aligned bases: the entry checks), else one.
+template <typename TS, typename TD, bool VEC4>
+__global__ void cast_pad(const TS* __restrict__ src, int M, int N, int lds, TD* __restrict__ dst, int ldd) {
+    constexpr int V = VEC4 ? 4 : 1;
+    const int ldv = ldd / V;
+    const long total = (long)M * ldv;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int n = i % ldd;
-        const long m = i / ldd;
-        dst[i] = from_f32<TD>(n < N ? to_f32(src[m * lds + n]) : 0.f);
+        const int n = (int)(i % ldv) * V;
+        const long m = i / ldv;
+        if constexpr (VEC4) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (n < N) {
+                if constexpr (sizeof(TS) == 4) {
+                    load4(reinterpret_cast<const float*>(src) + m * lds + n, v);
+                } else {
+                    const bf16x4 t = *reinterpret_cast<const bf16x4*>(src + m * lds + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (float)t[e];
+                }
+            }
+            store4<TD>(dst + m * ldd + n, v);
+        } else {
+            dst[m * ldd + n] = from_f32<TD>(n < N ? to_f32(src[m * lds + n]) : 0.f);
+        }
     }
 }
 
@@ -229,45 +246,64 @@ __global__ void embed_bwd(const long* q, const float* dx, int B, int Tn, int E, 
 
 // ---------------------------------------------------------------------------------------- GRU gates
 // gi, gh: [B][3H] (gate rows r,z,n; biases already added).  h' = (1-z) n + z h.   saved: r, z, n, hn = gh_n.
+// One thread = 4 consecutive hidden units of one sample (float4 loads, 8- or 16-byte stores; H % 4 == 0): with one
+// unit per thread and 2-byte scattered stores the backward kernel took 16 us per time step for ~10 MB.
 template <typename T>
-__global__ void gru_gate_fwd(const float* gi, const float* gh, const float* hprev, int B, int H, float* hnew, T* hnew_t,
-                             float* save /* [B][4H] */) {
-    const long total = (long)B * H;
+__global__ void gru_gate_fwd(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ hprev,
+                             int B, int H, float* __restrict__ hnew, T* __restrict__ hnew_t,
+                             float* __restrict__ save /* [B][4H] */) {
+    const int HV = H / 4;
+    const long total = (long)B * HV;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int j = i % H;
-        const long b = i / H;
-        const float* gib = gi + b * 3 * H;
-        const float* ghb = gh + b * 3 * H;
-        const float r = sigmoidf_(gib[j] + ghb[j]);
-        const float z = sigmoidf_(gib[H + j] + ghb[H + j]);
-        const float hn = ghb[2 * H + j];
-        const float n = tanhf(gib[2 * H + j] + r * hn);
-        const float h = (1.f - z) * n + z * hprev[i];
-        hnew[i] = h;
-        hnew_t[i] = from_f32<T>(h);
-        float* s = save + b * 4 * H;
-        s[j] = r; s[H + j] = z; s[2 * H + j] = n; s[3 * H + j] = hn;
+        const int j = (int)(i % HV) * 4;
+        const long b = i / HV;
+        const float* gib = gi + b * 3 * H + j;
+        const float* ghb = gh + b * 3 * H + j;
+        float ir[4], iz[4], in[4], hr[4], hz[4], hn[4], hp[4], r[4], z[4], n[4], h[4];
+        load4(gib, ir); load4(gib + H, iz); load4(gib + 2 * H, in);
+        load4(ghb, hr); load4(ghb + H, hz); load4(ghb + 2 * H, hn);
+        load4(hprev + b * H + j, hp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r[e] = sigmoidf_(ir[e] + hr[e]);
+            z[e] = sigmoidf_(iz[e] + hz[e]);
+            n[e] = tanhf(in[e] + r[e] * hn[e]);
+            h[e] = (1.f - z[e]) * n[e] + z[e] * hp[e];
+        }
+        store4<float>(hnew + b * H + j, h);
+        store4<T>(hnew_t + b * H + j, h);
+        float* sv = save + b * 4 * H + j;
+        store4<float>(sv, r); store4<float>(sv + H, z); store4<float>(sv + 2 * H, n); store4<float>(sv + 3 * H, hn);
     }
 }
 // dgi = [dr, dz, dn], dgh = [dr, dz, dn*r]  (MFMA dtype, [B][3H]);  dhprev = dh * z  (the W_hh term is added by a GEMM)
 template <typename T>
-__global__ void gru_gate_bwd(const float* dh, const float* save, const float* hprev, int B, int H, T* dgi, T* dgh,
-                             float* dhprev) {
-    const long total = (long)B * H;
+__global__ void gru_gate_bwd(const float* __restrict__ dh, const float* __restrict__ save,
+                             const float* __restrict__ hprev, int B, int H, T* __restrict__ dgi, T* __restrict__ dgh,
+                             float* __restrict__ dhprev) {
+    const int HV = H / 4;
+    const long total = (long)B * HV;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int j = i % H;
-        const long b = i / H;
-        const float* s = save + b * 4 * H;
-        const float r = s[j], z = s[H + j], n = s[2 * H + j], hn = s[3 * H + j];
-        const float g = dh[i];
-        const float dn = g * (1.f - z) * (1.f - n * n);
-        const float dz = g * (hprev[i] - n) * z * (1.f - z);
-        const float dr = dn * hn * r * (1.f - r);
-        T* a = dgi + b * 3 * H;
-        T* c = dgh + b * 3 * H;
-        a[j] = from_f32<T>(dr); a[H + j] = from_f32<T>(dz); a[2 * H + j] = from_f32<T>(dn);
-        c[j] = from_f32<T>(dr); c[H + j] = from_f32<T>(dz); c[2 * H + j] = from_f32<T>(dn * r);
-        dhprev[i] = g * z;
+        const int j = (int)(i % HV) * 4;
+        const long b = i / HV;
+        const float* sv = save + b * 4 * H + j;
+        float r[4], z[4], n[4], hn[4], g[4], hp[4], dr[4], dz[4], dn[4], dnr[4], dp[4];
+        load4(sv, r); load4(sv + H, z); load4(sv + 2 * H, n); load4(sv + 3 * H, hn);
+        load4(dh + b * H + j, g);
+        load4(hprev + b * H + j, hp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dn[e] = g[e] * (1.f - z[e]) * (1.f - n[e] * n[e]);
+            dz[e] = g[e] * (hp[e] - n[e]) * z[e] * (1.f - z[e]);
+            dr[e] = dn[e] * hn[e] * r[e] * (1.f - r[e]);
+            dnr[e] = dn[e] * r[e];
+            dp[e] = g[e] * z[e];
+        }
+        T* a = dgi + b * 3 * H + j;
+        T* c = dgh + b * 3 * H + j;
+        store4<T>(a, dr); store4<T>(a + H, dz); store4<T>(a + 2 * H, dn);
+        store4<T>(c, dr); store4<T>(c + H, dz); store4<T>(c + 2 * H, dnr);
+        store4<float>(dhprev + b * H + j, dp);
     }
 }
 
@@ -675,15 +711,20 @@ extern "C" int vqa_wn_bwd_all(void* stream, int n, const void* const* dw, const 
 
 extern "C" int vqa_cast_pad(void* stream, int src_dtype, int dst_dtype, const void* src, int M, int N, int lds,
                             void* dst, int ldd) {
-    dim3 grid(grid1d((long)M * ldd));
-    if (src_dtype == VQA_F32 && dst_dtype == VQA_BF16)
-        hipLaunchKernelGGL((cast_pad<float, bf16>), grid, dim3(256), 0, ST, (const float*)src, M, N, lds, (bf16*)dst, ldd);
-    else if (src_dtype == VQA_F32 && dst_dtype == VQA_F32)
-        hipLaunchKernelGGL((cast_pad<float, float>), grid, dim3(256), 0, ST, (const float*)src, M, N, lds, (float*)dst, ldd);
-    else if (src_dtype == VQA_BF16 && dst_dtype == VQA_F32)
-        hipLaunchKernelGGL((cast_pad<bf16, float>), grid, dim3(256), 0, ST, (const bf16*)src, M, N, lds, (float*)dst, ldd);
-    else
-        return VQA_ERR_ARG;
+    const bool v4 = N % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    const long items = (long)M * (v4 ? ldd / 4 : ldd);
+    dim3 grid((unsigned)((items + 255) / 256 > 0 ? (items + 255) / 256 : 1));     // one item per thread
+#define GO(TS, TD)                                                                                                  \
+    do {                                                                                                            \
+        if (v4) hipLaunchKernelGGL((cast_pad<TS, TD, true>), grid, dim3(256), 0, ST, (const TS*)src, M, N, lds, (TD*)dst, ldd); \
+        else hipLaunchKernelGGL((cast_pad<TS, TD, false>), grid, dim3(256), 0, ST, (const TS*)src, M, N, lds, (TD*)dst, ldd);   \
+    } while (0)
+    if (src_dtype == VQA_F32 && dst_dtype == VQA_BF16) GO(float, bf16);
+    else if (src_dtype == VQA_F32 && dst_dtype == VQA_F32) GO(float, float);
+    else if (src_dtype == VQA_BF16 && dst_dtype == VQA_F32) GO(bf16, float);
+    else return VQA_ERR_ARG;
+#undef GO
     CHECK_LAUNCH();
     return VQA_OK;
 }
@@ -704,7 +745,8 @@ extern "C" int vqa_embed_bwd(void* stream, const long* q, const float* dx, int B
 
 extern "C" int vqa_gru_gate_fwd(void* stream, int dtype, const float* gi, const float* gh, const float* hprev, int B,
                                 int H, float* hnew, void* hnew_t, float* save) {
-    dim3 grid(grid1d((long)B * H));
+    if (H % 4) return VQA_ERR_ARG;
+    dim3 grid((unsigned)(((long)B * (H / 4) + 255) / 256));
     BY_T(dtype, hipLaunchKernelGGL(gru_gate_fwd<bf16>, grid, dim3(256), 0, ST, gi, gh, hprev, B, H, hnew, (bf16*)hnew_t, save),
          hipLaunchKernelGGL(gru_gate_fwd<float>, grid, dim3(256), 0, ST, gi, gh, hprev, B, H, hnew, (float*)hnew_t, save));
     CHECK_LAUNCH();
@@ -713,7 +755,8 @@ extern "C" int vqa_gru_gate_fwd(void* stream, int dtype, const float* gi, const 
 
 extern "C" int vqa_gru_gate_bwd(void* stream, int dtype, const float* dh, const float* save, const float* hprev, int B,
                                 int H, void* dgi, void* dgh, float* dhprev) {
-    dim3 grid(grid1d((long)B * H));
+    if (H % 4) return VQA_ERR_ARG;
+    dim3 grid((unsigned)(((long)B * (H / 4) + 255) / 256));
     BY_T(dtype, hipLaunchKernelGGL(gru_gate_bwd<bf16>, grid, dim3(256), 0, ST, dh, save, hprev, B, H, (bf16*)dgi, (bf16*)dgh, dhprev),
          hipLaunchKernelGGL(gru_gate_bwd<float>, grid, dim3(256), 0, ST, dh, save, hprev, B, H, (float*)dgi, (float*)dgh, dhprev));
     CHECK_LAUNCH();

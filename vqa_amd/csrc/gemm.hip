@@ -300,7 +300,58 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
     }
     TC* C = static_cast<TC*>(g.C);
     const bool vec_ok = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
-                        (g.C2 == nullptr || g.ldc2 % 4 == 0);
+                        (g.C2 == nullptr || (g.ldc2 % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C2) & 7) == 0));
+    if (vec_ok && n0 + BN_ <= g.N && (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0) {
+        // Whole-tile case: after the MFMAs a lane owns 4 consecutive n of ONE m, so a store instruction would scatter
+        // 16 rows x 32- or 64-byte pieces.  Each wave passes its 16 m x (TNT*16) n block through LDS (free after the
+        // loop's last barrier) and writes whole row segments: 128 (bf16) or 256 (f32) contiguous bytes per row.
+        constexpr int EROW = TNT * 16 * 4 + 16, VPR = TNT * 4;      // LDS row bytes (f32), 4-element vectors per row
+        unsigned char* ew = dl + wave * 16 * EROW;
+        const int nb = n0 + wn * TNT * 16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + (wm * TM + i) * 16;
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) {
+                const int m = mb + r, n = nb + j * 16 + q * 4;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+                if (m < g.M) {
+                    if (g.bias) {
+                        const float4 t = *reinterpret_cast<const float4*>(g.bias + n);
+                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                    }
+                    if (g.rowadd) {
+                        const float* ra = g.rowadd + (long)(m / g.rowadd_group) * g.N + n;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += ra[e];
+                    }
+                    if (g.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (g.accumulate) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += to_f32(C[(long)m * g.ldc + n + e]);
+                    }
+                }
+                *reinterpret_cast<float4*>(ew + r * EROW + (j * 16 + q * 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int it = 0; it < 16 * VPR / 64; ++it) {
+                const int idx = it * 64 + lane, row = idx / VPR, c = idx % VPR;
+                const float4 t = *reinterpret_cast<const float4*>(ew + row * EROW + c * 16);
+                const int m = mb + row;
+                if (m < g.M) {
+                    const float o[4] = {t.x, t.y, t.z, t.w};
+                    store_vec4<TC>(C + (long)m * g.ldc + nb + c * 4, o);
+                    if (g.C2) store_vec4<bf16>(g.C2 + (long)m * g.ldc2 + nb + c * 4, o);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + (wm * TM + i) * 16 + r;

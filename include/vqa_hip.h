@@ -50,12 +50,14 @@ int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int OH, int OW, 
  * (in_dtype f16 / f32 / bf16; dataset.py:96-98 stores f16) - no NHWC copy, no channel padding: k = (c, ky, kx) = 27
  * is one 32-deep MFMA.  w is the f32 master weight [16][3][3][3]; y is NHWC bf16 [B][OH][OW][16]; G persistent
  * workgroups (<= tiles * B) walk the tiles, stats = [G][16][2] as in vqa_conv3x3_fwd.
- * _wgrad: dw [16][3][3][3] f32 from dy (NHWC bf16) and the image; part = [G][16][32] f32. */
+ * _wgrad: dw [16][3][3][3] f32 from dy (NHWC bf16) and the image; part = [G][16][32] f32.
+ * flip != 0 reads every image mirrored along its width: the whole-batch RandomHorizontalFlip of the training loop
+ * (vqa_model.py:250, model.flip) without a flipped copy of the batch. */
 int vqa_conv3x3_first_fwd(void* stream, int in_dtype, const void* images, const float* w, void* y, const float* bias,
                           float* stats, int B, int IH, int IW, int OH, int OW, int pad, int R, int CW, int G,
-                          const float* wscale /* NULL or [16]: folded into w */, int relu);
+                          const float* wscale /* NULL or [16]: folded into w */, int relu, int flip);
 int vqa_conv3x3_first_wgrad(void* stream, int in_dtype, const void* images, const void* dy, float* part, float* dw,
-                            int G, int B, int IH, int IW, int OH, int OW, int pad, int R, int CW);
+                            int G, int B, int IH, int IW, int OH, int OW, int pad, int R, int CW, int flip);
 
 /* Conv2d weight gradient (autograd of cnn.py:23-40): dw [Cout][Cin_real][3][3] f32 = sum over pixels of dy (x) x.
  * `part` is a [G][Cout][9][Cin] f32 workspace (one partial slab per workgroup group, summed in fixed order). */

@@ -81,6 +81,13 @@ def test_first_layer_exact(img_dtype, B, H, W, pad):
     xd = C.to_nhwc(img, torch.bfloat16)
     y2, _ = C.conv_fwd(xd, C.pack_weights(w.cuda(), C.CIN0_PAD, torch.bfloat16, dgrad=False), bias.cuda(), 16, pad, True)
     assert torch.equal(y2, y)
+    # mirrored read (the training loop's whole-batch horizontal flip): equal to the kernels on the flipped batch
+    imgf = img.flip(-1).contiguous()
+    ym, sm = C.first_fwd(img, w.cuda(), bias.cuda(), pad, True, mirror=True)
+    yf, sf = C.first_fwd(imgf, w.cuda(), bias.cuda(), pad, True)
+    assert torch.equal(ym, yf) and torch.equal(sm, sf)
+    dyd = _nhwc(dy, torch.bfloat16)
+    assert torch.equal(C.first_wgrad(img, dyd, pad, mirror=True), C.first_wgrad(imgf, dyd, pad))
 
 
 @pytest.mark.parametrize('prec,tol', [('fp32', 1e-5), ('bf16', 2e-2)])

@@ -246,3 +246,24 @@ def test_edge_shapes_vs_oracle(B, T, H, W, tmp_path):
             continue                                         # ReLU / arg-max flip band at tiny batches
         tol = 2e-3 if k.endswith('weight_g') else 5e-4
         assert rel_err(p.grad.detach().cpu(), o_grads[k]) < tol, k
+
+
+@pytest.mark.parametrize('prec', ['bf16', 'fp32'])
+def test_mirror_equals_flipped_batch(prec, tmp_path):
+    """model(images, q, mirror=True) == model(images.flip(-1), q): logits and every gradient, bit for bit (the bf16
+    path reads the images mirrored inside the first-layer kernels, the fp32 path flips the batch)."""
+    import vqa_model
+    c = load_case('h64_p5_max')
+    img, q, t = c['images'].cuda(), c['questions'].cuda(), c['targets'].cuda()
+    out = []
+    for mirror in (True, False):
+        m = build_model(c, tmp_path, prec).cuda().train()
+        logits = m(img, q, mirror=True) if mirror else m(img.flip(-1).contiguous(), q)
+        vqa_model.SoftScoreBCELoss()(logits, t).backward()
+        out.append((logits.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+    assert torch.equal(out[0][0], out[1][0])
+    for k in out[0][1]:
+        if k == 'gru.word_embedding.weight':                 # float atomics in the scatter-add
+            assert torch.allclose(out[0][1][k], out[1][1][k], rtol=1e-5, atol=1e-7)
+        else:
+            assert torch.equal(out[0][1][k], out[1][1][k]), k

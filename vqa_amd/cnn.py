@@ -176,7 +176,7 @@ def first_ok(images, w, dtype):
             images.shape[1] == 3 and images.dtype in (torch.float16, torch.float32, torch.bfloat16))
 
 
-def first_fwd(images, w, bias, pad, want_stats, wscale=None, relu=False):
+def first_fwd(images, w, bias, pad, want_stats, wscale=None, relu=False, mirror=False):
     B, _, IH, IW = images.shape
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
     R, CW = pick_tile(OH, OW)
@@ -186,11 +186,11 @@ def first_fwd(images, w, bias, pad, want_stats, wscale=None, relu=False):
     tag = dict(kind='first', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
                bytes=float(images.numel() * images.element_size() + y.numel() * 2 + w.numel() * 4))
     L.call('vqa_conv3x3_first_fwd', L.dt(images), images, w, y, bias, stats, B, IH, IW, OH, OW, pad, R, CW, G,
-           wscale, int(relu), tag=tag)
+           wscale, int(relu), int(mirror), tag=tag)
     return y, stats
 
 
-def first_wgrad(images, dy, pad, out=None):
+def first_wgrad(images, dy, pad, out=None, mirror=False):
     B, _, IH, IW = images.shape
     _, OH, OW, _ = dy.shape
     R, CW = pick_tile(OH, OW)
@@ -200,16 +200,17 @@ def first_wgrad(images, dy, pad, out=None):
     dw = out if out is not None else torch.empty(16, 3, 3, 3, device=dy.device, dtype=torch.float32)
     tag = dict(kind='first_wgrad', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
                bytes=float(images.numel() * images.element_size() + dy.numel() * 2))
-    L.call('vqa_conv3x3_first_wgrad', L.dt(images), images, dy, part, dw, G, B, IH, IW, OH, OW, pad, R, CW, tag=tag)
+    L.call('vqa_conv3x3_first_wgrad', L.dt(images), images, dy, part, dw, G, B, IH, IW, OH, OW, pad, R, CW,
+           int(mirror), tag=tag)
     return dw
 
 
-def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False, wpk=None):
+def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False, wpk=None, mirror=False):
     """conv3x3 -> BatchNorm -> ReLU -> (pool).  x NHWC (first=True: the NCHW image, dedicated kernel).  Returns
     (a, saved) with saved = (x, y, scale, shift, mean, invstd) for block_bwd."""
     dev, cout = x.device, w.shape[0]
     if first:
-        y, stats = first_fwd(x, w, bias, pad, training)
+        y, stats = first_fwd(x, w, bias, pad, training, mirror=mirror)
     else:
         if wpk is None:
             wpk = pack_weights(w, x.shape[3], x.dtype, dgrad=False)
@@ -228,7 +229,7 @@ def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False,
     return a, (x, y, scale, shift, mean, invstd)
 
 
-def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None, params=None):
+def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None, params=None, mirror=False):
     """d = gradient w.r.t. the block output (NHWC, activation dtype).  Returns (dx, dw, dbias, dgamma, dbeta)."""
     x, y, scale, shift, mean, invstd = saved
     dev = y.device
@@ -254,7 +255,8 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
                                         L.ptr(dbeta), L.ptr(c1), L.ptr(c2)), 'vqa_bn_bwd_finalize')
     tag = dict(kind='apply', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((2 * y.numel() + d.numel()) * es))
     L.call('vqa_bn_bwd', L.dt(y), 1, y, d, dy, scale, shift, mean, invstd, c1, c2, None, B, H, W, C, pool, tag=tag)
-    dw = first_wgrad(x, dy, pad, out=dw_out) if first else conv_wgrad(x, dy, cin_real, pad, out=dw_out)
+    dw = (first_wgrad(x, dy, pad, out=dw_out, mirror=mirror) if first
+          else conv_wgrad(x, dy, cin_real, pad, out=dw_out))
     # the conv bias feeds a training-mode BatchNorm: its gradient is identically zero (the reference produces
     # rounding noise ~1e-7 of the weight-gradient scale here)
     # (its slot in the flat gradient buffer is never written: zero from FlatParams' initial fill)
@@ -313,9 +315,12 @@ class _CnnFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, images, cfg, *tensors):
-        padding, pool_mode, training, dtype = cfg
+        padding, pool_mode, training, dtype, mirror = cfg
         params, buffers = tensors[:40], tensors[40:]
         first = first_ok(images, params[0], dtype)
+        if mirror and not (first and training):
+            # the mirrored read lives in the first-layer training kernels; everywhere else flip the batch itself
+            images, mirror = images.flip(-1), False
         x = images.contiguous() if first else to_nhwc(images, dtype)
         if not training:
             ctx.cfg = cfg
@@ -333,17 +338,17 @@ class _CnnFunction(torch.autograd.Function):
             pad = padding if li in (0, 2, 4, 6) else 0
             pool = pool_mode if li % 2 == 1 else 0
             x, sv = block_fwd(x, w, bias, gamma, beta, buffers[2 * li], buffers[2 * li + 1], pad, pool, training,
-                              first=first and li == 0, wpk=wf[li])
+                              first=first and li == 0, wpk=wf[li], mirror=mirror and li == 0)
             saved += list(sv)
             meta.append((pad, pool))
         ctx.save_for_backward(*saved, *params)
-        ctx.meta, ctx.cfg, ctx.first = meta, cfg, first
+        ctx.meta, ctx.cfg, ctx.first, ctx.mirror = meta, cfg, first, mirror
         B, PH, PW, C = x.shape
         return x.reshape(B, PH * PW, C).float()
 
     @staticmethod
     def backward(ctx, dout):
-        padding, pool_mode, training, dtype = ctx.cfg
+        padding, pool_mode, training, dtype, _ = ctx.cfg
         if not training:
             raise L.VqaHipError('CNN backward is implemented for training-mode BatchNorm only')
         saved, params = ctx.saved_tensors[:60], ctx.saved_tensors[60:]
@@ -355,6 +360,7 @@ class _CnnFunction(torch.autograd.Function):
             pad, pool = ctx.meta[li]
             d, dw, db, dg, dbt = block_bwd(d, saved[6 * li: 6 * li + 6], params[4 * li], CHANNELS[li], pad, pool,
                                            li > 0, first=ctx.first and li == 0, wpk_d=ctx.wd[li],
+                                           mirror=ctx.mirror and li == 0,
                                            params=params[4 * li: 4 * li + 4])
             grads[4 * li: 4 * li + 4] = [dw, db, dg, dbt]
         return (None, None, *grads, *([None] * 20))
@@ -380,7 +386,9 @@ class CNN(nn.Module):
         # The Sequential only HOLDS the parameters / buffers under the reference's names; it is never called.
         self.convolutions = nn.Sequential(*layers)
 
-    def forward(self, x):
+    def forward(self, x, mirror=False):
+        """mirror=True encodes the batch flipped along its width (the reference flips the batch tensor before the
+        call, vqa_model.py:250; here the first layer reads it mirrored instead)."""
         if not x.is_cuda:
             raise L.VqaHipError('vqa_amd.CNN runs on an MI355X only (no CPU fallback); move the model and inputs '
                                 'to cuda')
@@ -390,7 +398,7 @@ class CNN(nn.Module):
             conv, bn = self.convolutions[ci], self.convolutions[ci + 1]
             params += [conv.weight, conv.bias, bn.weight, bn.bias]
             buffers += [bn.running_mean, bn.running_var]
-        cfg = (self.padding, 1 if self.pooling == 'max' else 2, self.training, dtype)
+        cfg = (self.padding, 1 if self.pooling == 'max' else 2, self.training, dtype, bool(mirror))
         out = _CnnFunction.apply(x, cfg, *params, *buffers)
         if self.training:
             with torch.no_grad():                  # ten counters, one launch

@@ -21,6 +21,8 @@ struct FirstArgs {
     float inv_cw, inv_pw, inv_tx, inv_tiles;
     const float* wscale; // fwd: per-output-channel factor folded into the weights (eval-mode BatchNorm) or null
     int relu;            // fwd: y = max(conv + bias, 0)
+    int flip;            // read every image mirrored along its width: the reference's whole-batch RandomHorizontalFlip
+                         // (vqa_model.py:250) costs nothing here - only the sign of the patch's x step changes
 };
 
 constexpr int PMAX = 384;                       // host bound on (R+2)*(CW+2)
@@ -44,7 +46,7 @@ __device__ __forceinline__ void plan_patch(const FirstArgs& a, int PW, int PP, P
         const int i = tid + j * 256;
         const int c = fastdiv(i, PP, inv_pp), rem = i - c * PP;
         const int py = fastdiv(rem, PW, a.inv_pw), px = rem - py * PW;
-        pl.rel[j] = c * a.IH * a.IW + (py - a.pad) * a.IW + (px - a.pad);
+        pl.rel[j] = c * a.IH * a.IW + (py - a.pad) * a.IW + (a.flip ? a.pad - px : px - a.pad);
         pl.pyx[j] = ((c < 3 ? py - a.pad : -0x4000) << 16) | (px - a.pad + 64);
     }
 }
@@ -54,7 +56,7 @@ __device__ __forceinline__ void plan_patch(const FirstArgs& a, int PW, int PP, P
 template <typename TI>
 __device__ __forceinline__ void fetch_patch(const FirstArgs& a, const TI* img, const PatchPlan& pl, int b, int oy0,
                                             int ox0, float (&v)[NIV], unsigned& okbits) {
-    const int org = oy0 * a.IW + ox0;
+    const int org = oy0 * a.IW + (a.flip ? a.IW - 1 - ox0 : ox0);     // (mirrored column: in range iff the column is)
     const TI* it = img + (long)b * 3 * a.IH * a.IW + org;
     okbits = 0;
 #pragma unroll
@@ -330,10 +332,11 @@ bool first_args(FirstArgs& a, int B, int IH, int IW, int OH, int OW, int pad, in
 
 extern "C" int vqa_conv3x3_first_fwd(void* stream, int in_dtype, const void* images, const float* w, void* y,
                                      const float* bias, float* stats, int B, int IH, int IW, int OH, int OW, int pad,
-                                     int R, int CW, int G, const float* wscale, int relu) {
+                                     int R, int CW, int G, const float* wscale, int relu, int flip) {
     FirstArgs a{images, w, static_cast<bf16*>(y), bias, stats};
     a.wscale = wscale;
     a.relu = relu;
+    a.flip = flip;
     if (!images || !w || !y || !first_args(a, B, IH, IW, OH, OW, pad, R, CW)) return VQA_ERR_ARG;
     if (G < 1 || G > a.tiles_x * a.tiles_y * B) return VQA_ERR_ARG;
     size_t lds = (size_t)3 * (R + 2) * (CW + 2) * 2;
@@ -350,10 +353,11 @@ extern "C" int vqa_conv3x3_first_fwd(void* stream, int in_dtype, const void* ima
 
 extern "C" int vqa_conv3x3_first_wgrad(void* stream, int in_dtype, const void* images, const void* dy, float* part,
                                        float* dw, int G, int B, int IH, int IW, int OH, int OW, int pad, int R,
-                                       int CW) {
+                                       int CW, int flip) {
     FirstArgs a{images, nullptr, static_cast<bf16*>(const_cast<void*>(dy)), nullptr, part};
     a.wscale = nullptr;
     a.relu = 0;
+    a.flip = flip;
     if (!images || !dy || !part || !dw || G < 1 || !first_args(a, B, IH, IW, OH, OW, pad, R, CW)) return VQA_ERR_ARG;
     const int MTP = (R * CW + 31) / 32 * 32;
     if (G > a.tiles_x * a.tiles_y * B) return VQA_ERR_ARG;

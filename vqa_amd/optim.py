@@ -160,9 +160,9 @@ class Trainer:
 
     def step(self, images, questions, target, flip=True):
         self.opt.zero_grad()
-        if flip:
-            images = self.model.flip(images)
-        logits = self.model(images, questions)
+        # the reference flips the batch tensor (vqa_model.py:250); same coin, but the first conv reads it mirrored
+        mirror = flip and self.model.flip.draw()
+        logits = self.model(images, questions, mirror=mirror)
         loss = self.criterion(logits, target)
         loss.backward()
         if not self.buckets.active:

@@ -42,8 +42,12 @@ class RandomHorizontalFlip(nn.Module):
         super().__init__()
         self.p = p
 
+    def draw(self):
+        """The coin of one forward() call (same draw from torch's CPU generator)."""
+        return bool(torch.rand(1) < self.p)
+
     def forward(self, img):
-        return img.flip(-1) if torch.rand(1) < self.p else img
+        return img.flip(-1) if self.draw() else img
 
 
 class WeightNormLinear(nn.Module):
@@ -203,7 +207,8 @@ class VQA(nn.Module):
         keep = 1.0 - self.dropout_p
         return torch.empty(B, self.hidden_dim, device=dev).bernoulli_(keep).div_(keep)
 
-    def forward(self, images_batch, questions_batch):
+    def forward(self, images_batch, questions_batch, mirror=False):
+        # mirror=True: the batch as model.flip would have flipped it, without the flipped copy (Trainer.step)
         if not images_batch.is_cuda:
             raise L.VqaHipError('vqa_amd.VQA runs on an MI355X only: there is no CPU fallback for the hot path')
         # The question encoder (28 small latency-bound launches per direction) is independent of the image
@@ -215,11 +220,11 @@ class VQA(nn.Module):
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 questions_representation = self.gru(questions_batch)    # [B, H]
-            images_representation = self.cnn(images_batch)              # [B, k, d]
+            images_representation = self.cnn(images_batch, mirror)      # [B, k, d]
             cur.wait_stream(side)
             questions_representation.record_stream(cur)
         else:
-            images_representation = self.cnn(images_batch)
+            images_representation = self.cnn(images_batch, mirror)
             questions_representation = self.gru(questions_batch)
         dtype = torch.bfloat16 if self.precision == 'bf16' else torch.float32
         B = images_batch.shape[0]

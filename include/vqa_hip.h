@@ -40,7 +40,8 @@ int vqa_conv_pack_all(void* stream, int dtype, int n, const void* const* w, void
  * when called on dy with a dgrad slab and pad' = 2 - pad.  y = conv(x) + bias.  R x CW (<= 256 pixels) is the output
  * tile; G persistent workgroups per output-channel block walk the (image, tile) pairs - take G from
  * vqa_conv3x3_plan() (resident workgroups of the instantiation x 256 CUs; -1 = unsupported shape).  `stats` (may be
- * NULL) receives G rows of per-channel (sum, sum of squares) of y, [G][Cout][2], for the BatchNorm that follows. */
+ * NULL) receives G rows of per-channel (sum, sum of squares) of y, [G][Cout][2], for the BatchNorm that follows.
+ * x and y are addressed through 32-bit byte offsets (buffer resources): each must be smaller than 4 GiB. */
 int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked, void* y, const float* bias,
                     float* stats, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW,
                     int G, int relu /* 1: y = max(conv + bias, 0) - eval mode with the BatchNorm folded into w, bias */);
@@ -124,7 +125,7 @@ int vqa_embed_fwd(void* stream, int dtype, const long* q, const float* emb, int 
 /* its backward: demb[q[b][t]] += dx[t*B + b] (demb pre-zeroed). */
 int vqa_embed_bwd(void* stream, const long* q, const float* dx, int B, int T, int E, int lddx, float* demb);
 /* nn.GRU cell gates (gru.py:104): r, z, n and h' = (1-z) n + z h from the two projections gi, gh ([B][3H], biases
- * included); save = [B][4H] (r, z, n, W_hn h + b_hn) for the backward. */
+ * included); save = [B][4H] (r, z, n, W_hn h + b_hn) for the backward.  H % 4 == 0 (16-byte accesses). */
 int vqa_gru_gate_fwd(void* stream, int dtype, const float* gi, const float* gh, const float* hprev, int B, int H,
                      float* hnew, void* hnew_t, float* save);
 int vqa_gru_gate_bwd(void* stream, int dtype, const float* dh, const float* save, const float* hprev, int B, int H,
@@ -143,7 +144,8 @@ int vqa_gru_bwd_persistent(void* stream, const void* wt, int ldw, const float* h
 
 /* ---------------------------------------------------------------- attention / fusion head (vqa_model.py:83-103) */
 
-/* vqa_model.py:90-93: s = a . w_s per region, softmax over the K regions, vhat = sum_k p_k v[b,k,:]. */
+/* vqa_model.py:90-93: s = a . w_s per region, softmax over the K regions, vhat = sum_k p_k v[b,k,:].
+ * 16-byte accesses: H % 8 == 0 (bf16) / H % 4 == 0 (f32), D % 4 == 0, D <= 1024. */
 int vqa_attn_fwd(void* stream, int dtype, const void* a, const void* ws, const float* v, int B, int K, int H, int D,
                  float* p, float* vhat, void* vhat_t);
 int vqa_attn_bwd(void* stream, int dtype, const void* a, const void* ws, const float* v, const float* p,

@@ -34,6 +34,22 @@ def main():
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-5), k
         else:
             assert torch.equal(a, b), k
+    # evaluate() under an initialised process group: its 3-scalar all-reduce over one rank changes nothing
+    import contextlib
+    import io
+    import vqa_model
+
+    class DS:
+        phase, original_length = 'val', 7
+    batches = [{'image': c['images'], 'question': c['questions'], 'answer': c['targets']}]
+    with contextlib.redirect_stdout(io.StringIO()):
+        loss, _, acc = vqa_model.evaluate(batches, m1, vqa_model.SoftScoreBCELoss(), 0.0, DS())
+    m1.eval()
+    with torch.no_grad():
+        lo = m1(img, q)
+    from vqa_amd import ops
+    assert abs(acc - float(ops.soft_accuracy_sum(lo, t)) / 7) < 1e-9
+    assert abs(loss - float(vqa_model.SoftScoreBCELoss()(lo, t))) < 1e-3 * abs(loss)
     print('DP_GPU_OK', flush=True)
     dist.destroy_process_group()
 

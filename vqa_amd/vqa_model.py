@@ -275,20 +275,29 @@ def evaluate(dataloader, model, criterion, last_epoch_acc, dataset):
     model.eval()
     with torch.no_grad():
         acc_sum = None
-        epoch_losses = list()
+        epoch_losses = list()                           # device scalars: ONE host sync per evaluation, not per batch
         for i_batch, batch in enumerate(dataloader):
             images_batch = batch['image'].cuda()
             questions_batch = batch['question'].cuda()
-            target = batch['answer'].cuda()
+            target = batch['answer']
+            target = tuple(t.cuda() for t in target) if isinstance(target, (tuple, list)) else target.cuda()
             output = model(images_batch, questions_batch)
-            loss = criterion(output, target)
-            epoch_losses.append(float(loss))
+            epoch_losses.append(criterion(output, target).detach().reshape(1).float())
             part = ops.soft_accuracy_sum(output, target)
             acc_sum = part if acc_sum is None else acc_sum + part
-        accuracy = float(acc_sum) if acc_sum is not None else 0.0
+        dev = next(model.parameters()).device
+        totals = torch.zeros(3, device=dev, dtype=torch.float64)    # accuracy sum, loss sum, batches
+        if acc_sum is not None:
+            totals[0] = acc_sum.double().sum()
+            totals[1] = torch.cat(epoch_losses).double().sum()
+            totals[2] = len(epoch_losses)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # data-parallel evaluation: every rank saw its shard of the loader; one 3-scalar all-reduce
+            torch.distributed.all_reduce(totals, op=torch.distributed.ReduceOp.SUM)
+        accuracy, loss_sum, batches = (float(v) for v in totals.tolist())
         acc = accuracy / dataset.original_length
         print(f"{'Validation' if dataset.phase == 'val' else 'Train'} accuracy = {round(acc, 5)}")
-        cur_epoch_loss = float(np.mean(epoch_losses))
+        cur_epoch_loss = loss_sum / batches if batches else float('nan')
         print(f"{'Validation' if dataset.phase == 'val' else 'Train'} loss = {round(cur_epoch_loss, 5)}")
         acc_not_improved = not (acc > last_epoch_acc)
         return cur_epoch_loss, acc_not_improved, acc

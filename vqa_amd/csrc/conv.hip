@@ -50,6 +50,13 @@ template <typename T, int CK> struct ConvCfg {
     static constexpr int VPP = CK * (int)sizeof(T) / 16;     // 16-byte vectors per patch pixel
 };
 
+#ifdef VQA_STAMPS
+__device__ unsigned long long g_stamps[16384][12];
+#define STAMP(i) do { if (threadIdx.x == 0) { const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+                      if (wg < 16384) g_stamps[wg][i] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 // ---------------------------------------------------------------------------------------------- igemm
 // One workgroup per (tile, image, channel block): the multi-chunk (Cin > CK) layers, which are MFMA-bound and
 // want their registers for the accumulators and the chunk prefetch rather than for persistent-loop state.
@@ -66,6 +73,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
+    STAMP(0);
 
     const int tile = blockIdx.x, b = blockIdx.y, co0 = blockIdx.z * NB;
     const int ty = fastdiv(tile, a.tiles_x, a.inv_tx), tx = tile - ty * a.tiles_x;
@@ -159,10 +167,13 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     // unrolled k-steps costs the full tiles 10 %: it cuts the MFMA / LDS-read schedule into small blocks)
     auto chunks = [&](auto nf_tag) {
         constexpr int NF = decltype(nf_tag)::value;
+        STAMP(1);
         fetch(0);
         for (int ch = 0; ch < nchunks; ++ch) {
             stash();
+            if (ch == 0) STAMP(2);
             __syncthreads();
+            if (ch == 0) STAMP(3);
             if (ch + 1 < nchunks) fetch(ch + 1);
             // ---- MFMA over 9 taps x CK channels
 #pragma unroll
@@ -185,8 +196,11 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
 #pragma unroll
                     for (int n = 0; n < NBF; ++n) Mma<T>::mma(acc[f][n], fw[n], fp[f]);
             }
+            if (ch == 0) STAMP(4);
             __syncthreads();
+            if (ch == 0) STAMP(5);
         }
+        STAMP(6);
     };
     if (nfw >= 4) chunks(std::integral_constant<int, 4>{});
     else if (nfw == 3) chunks(std::integral_constant<int, 3>{});
@@ -228,6 +242,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
         case 2: finish(std::integral_constant<int, 2>{}); break;
         default: finish(std::integral_constant<int, 3>{}); break;
     }
+    STAMP(7);
     if (a.stats) {
         // [4 waves][NB][2] behind the transpose regions: the sums are ready before any global store is issued, so the
         // barrier below does not wait for stores
@@ -258,6 +273,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
         const int op = epix[p];
         if (op >= 0) *reinterpret_cast<uint4*>(y + (long)op * a.Cout + co0 + c * (16 / (int)sizeof(T))) = vv;
     }
+    STAMP(8);
 }
 
 
@@ -441,12 +457,11 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
 template <typename T, int CK, int NBF>
 size_t igemm_lds(const ConvArgs& a) {
     using Cfg = ConvCfg<T, CK>;
-    size_t lds = (size_t)(a.R + 2) * ((a.CW + 2) * Cfg::PXB + Cfg::RPAD) + (size_t)NBF * 16 * Cfg::WROWB +
-                 (size_t)NBF * 16 * 4;
-    if (lds < (size_t)4 * NBF * 16 * 2 * sizeof(float)) lds = (size_t)4 * NBF * 16 * 2 * sizeof(float);
-    const size_t epi = (size_t)4 * 64 * (NBF * 16 * sizeof(T) + 16) + 4 * 64 * 4 +   // tile kernel's store transpose
-                       (size_t)4 * NBF * 16 * 2 * 4;                                   // + its statistics rows
+    size_t lds = (size_t)(a.R + 2) * ((a.CW + 2) * Cfg::PXB + Cfg::RPAD) + (size_t)NBF * 16 * Cfg::WROWB;
+    const size_t epi = (size_t)4 * 64 * (NBF * 16 * sizeof(T) + 16) + 4 * 64 * 4 +   // tile kernels' store transpose
+                       (size_t)4 * NBF * 16 * 2 * 4;                                   // + their statistics rows
     if (lds < epi) lds = epi;
+    lds += (size_t)NBF * 16 * 4;                                                       // resident bias row
     return lds;
 }
 
@@ -881,6 +896,11 @@ extern "C" int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const voi
 }
 
 // G for vqa_conv3x3_fwd: persistent workgroups per output-channel block = rows of `stats`; -1 = unsupported shape
+#ifdef VQA_STAMPS
+extern "C" int vqa_debug_stamps(void* out) {     // host buffer of 16384 * 12 u64
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
 extern "C" int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R,
                                 int CW) {
     return conv_fwd_entry(nullptr, dtype, nullptr, nullptr, nullptr, nullptr, nullptr, B, IH, IW, Cin, OH, OW, Cout,

@@ -24,7 +24,7 @@ for _ in range(3):
         M.conv_fwd(dy, wpk_d, None, cin, 2 - pads[li], False, kind='dgrad')
 torch.cuda.synchronize()
 buf = np.zeros((16384, 12), dtype=np.uint64)
-assert L.lib().vqa_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+assert L.lib().dbg_conv_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 s = buf[buf[:, 8] > 0].astype(np.int64)
 names = ['decode+bias', 'fetch0 issue+stash0 (wait loads)', 'barrier', 'fetch1 issue + MFMA chunk0', 'barrier', 'chunks 1..', 'epilogue math+transpose', 'stats+row stores']
 d = np.diff(s[:, :9], axis=1)

@@ -897,7 +897,7 @@ extern "C" int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const voi
 
 // G for vqa_conv3x3_fwd: persistent workgroups per output-channel block = rows of `stats`; -1 = unsupported shape
 #ifdef VQA_STAMPS
-extern "C" int vqa_debug_stamps(void* out) {     // host buffer of 16384 * 12 u64
+extern "C" int dbg_conv_stamps(void* out) {     // host buffer of 16384 * 12 u64
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
 }
 #endif

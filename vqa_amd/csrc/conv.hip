@@ -79,7 +79,6 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     const int ty = fastdiv(tile, a.tiles_x, a.inv_tx), tx = tile - ty * a.tiles_x;
     const int oy0 = ty * a.R, ox0 = tx * a.CW;
     const int MT = a.R * a.CW;
-    const T* x = static_cast<const T*>(a.x);
     const T* w = static_cast<const T*>(a.w);
 
     // per-fragment pixel decode.  The tile's fragments of 16 consecutive pixels are dealt to the waves round-robin
@@ -118,11 +117,13 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     constexpr int NPV = (PMAX * VPP + 255) / 256;
     constexpr int WV = KP / VEC;                                // vectors per weight row
     constexpr int NWV = (NB * WV + 255) / 256;
-    const T* xb = x + (long)b * a.IH * a.IW * a.Cin;
-    int psrc[NPV];                                              // element offset inside the image
+    // Out-of-image vectors get a byte offset >= 2^31, beyond the buffer (the launcher keeps x below 2 GiB): the
+    // hardware answers such a buffer load with zeros - the zero padding needs no mask at the LDS write.
+    const unsigned xbytes = (unsigned)a.B * a.IH * a.IW * a.Cin * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xbuf = buffer_of(a.x, xbytes);
+    const unsigned img0 = (unsigned)b * a.IH * a.IW * a.Cin * (unsigned)sizeof(T);
+    unsigned psrc[NPV];                                         // byte offset inside the image, or 0x80000000
     int pdst[NPV];                                              // byte offset inside the LDS patch
-    unsigned pmask[NPV];                                        // all-ones, or 0 = zero fill (AND, not a select: a
-                                                                // select lets hipcc branch around the load again)
 #pragma unroll
     for (int j = 0; j < NPV; ++j) {
         const int i = tid + j * 256;
@@ -130,16 +131,14 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
         const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
         const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
         const bool ok = i < PPIX * VPP && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
-        psrc[j] = ok ? (iy * a.IW + ix) * a.Cin + vv * VEC : 0;
+        psrc[j] = ok ? (unsigned)((iy * a.IW + ix) * a.Cin + vv * VEC) * (unsigned)sizeof(T) : 0x80000000u;
         pdst[j] = py * PROWB + pxx * PXB + vv * 16;
-        pmask[j] = ok ? 0xFFFFFFFFu : 0u;
     }
     uint4 pv[NPV], wv[NWV];
     auto fetch = [&](int ch) {
+        const unsigned base = img0 + (unsigned)(ch * CK) * (unsigned)sizeof(T);
 #pragma unroll
-        for (int j = 0; j < NPV; ++j) {
-            pv[j] = *reinterpret_cast<const uint4*>(xb + psrc[j] + ch * CK);   // masked in stash(): no wait here
-        }
+        for (int j = 0; j < NPV; ++j) pv[j] = buffer_load16(xbuf, psrc[j] + base);
         const T* wsrc = w + ((long)ch * a.Cout + co0) * KP;     // the chunk's NB rows are contiguous
 #pragma unroll
         for (int j = 0; j < NWV; ++j) {
@@ -151,13 +150,13 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NPV; ++j) {
             const int i = tid + j * 256;
-            const uint4 t = make_uint4(pv[j].x & pmask[j], pv[j].y & pmask[j], pv[j].z & pmask[j], pv[j].w & pmask[j]);
+            const uint4 t = pv[j];   // by value first: a conditional store straight from the array keeps it in scratch
             if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + pdst[j]) = t;
         }
 #pragma unroll
         for (int j = 0; j < NWV; ++j) {
             const int i = tid + j * 256;
-            const uint4 t = wv[j];   // by value first: a conditional store straight from the array keeps it in scratch
+            const uint4 t = wv[j];
             if (i < NB * WV) *reinterpret_cast<uint4*>(wl + (i / WV) * WROWB + (i % WV) * 16) = t;
         }
     };
@@ -492,6 +491,7 @@ int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
         hipLaunchKernelGGL(kp, dim3(G, zb), dim3(256), lds, s, a);
     } else {
         if (G != total) return VQA_ERR_ARG;
+        if ((double)a.B * a.IH * a.IW * a.Cin * sizeof(T) >= 2147483648.0) return VQA_ERR_ARG;   // (offset sentinel 2^31)
         hipLaunchKernelGGL(kt, dim3(a.tiles_x * a.tiles_y, a.B, zb), dim3(256), lds, s, a);
     }
     CHECK_LAUNCH();

@@ -554,8 +554,6 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     const int nco = a.Cout / COW;
     const int co0 = (blockIdx.y % nco) * COW, ci0 = (blockIdx.y / nco) * CK;
     const int wcf = wave % CF, wcg = (wave / CF) % NCG, wk = wave / (CF * NCG);
-    const T* x = static_cast<const T*>(a.x);
-    const T* dy = static_cast<const T*>(a.dy);
     const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
     if ((int)blockIdx.x >= total) return;
 
@@ -578,14 +576,14 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
         const int px = i / VPP, vv = i % VPP;
         const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
         pyx[j] = ((i < PPIX * VPP ? py - a.pad : -0x4000) << 16) | (pxx - a.pad + 64);
-        prel[j] = ((py - a.pad) * a.IW + (pxx - a.pad)) * a.Cin + ci0 + vv * VEC;
+        prel[j] = (((py - a.pad) * a.IW + (pxx - a.pad)) * a.Cin + ci0 + vv * VEC) * (int)sizeof(T);   // bytes
     }
 #pragma unroll
     for (int j = 0; j < NDV; ++j) {
         const int i = tid + j * 256, m = i >> dsh, vv = i & (dvp - 1);
         const int pr = fastdiv(m, a.CW, a.inv_cw), pc = m - pr * a.CW;
         drc[j] = ((m < MT ? pr : 0x4000) << 16) | pc;
-        drel[j] = (pr * a.OW + pc) * a.Cout + co0 + vv * VEC;
+        drel[j] = ((pr * a.OW + pc) * a.Cout + co0 + vv * VEC) * (int)sizeof(T);                        // bytes
     }
     for (int m = tid; m < MTP; m += 256) {
         const int mm = m < MT ? m : 0;                             // dy rows beyond the tile are zero: any finite x
@@ -595,43 +593,41 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
 
     // ---- software pipeline over pixel tiles: the (branch-free) global loads of tile t+1 are issued into registers
     // before the MFMA loop of tile t and written to LDS after it
+    // out-of-image patch vectors and dy rows beyond the tile / image are fetched at the buffers' sizes: the hardware
+    // returns zeros for them (no clamped address, no mask at the LDS write)
+    const unsigned xbytes = (unsigned)a.B * a.IH * a.IW * a.Cin * (unsigned)sizeof(T);      // (launcher: both < 4 GiB)
+    const unsigned dbytes = (unsigned)a.B * a.OH * a.OW * a.Cout * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xbuf = buffer_of(a.x, xbytes), dbuf = buffer_of(a.dy, dbytes);
     uint4 pv[NPV], dv[NDV];
-    unsigned pok = 0, dok = 0;
     auto fetch = [&](int t) {
         const int b = fastdiv(t, tiles, a.inv_tiles), tl = t - b * tiles;
         const int tyy = fastdiv(tl, a.tiles_x, a.inv_tx);
         const int oy0 = tyy * a.R, ox0 = (tl - tyy * a.tiles_x) * a.CW;
-        const int org = (oy0 * a.IW + ox0) * a.Cin;
-        const T* xt = x + (long)b * a.IH * a.IW * a.Cin + org;
-        const T* dt = dy + ((long)(b * a.OH + oy0) * a.OW + ox0) * a.Cout;
-        pok = dok = 0;
+        const unsigned xorg = (unsigned)((b * a.IH + oy0) * a.IW + ox0) * a.Cin * (unsigned)sizeof(T);
+        const unsigned dorg = (unsigned)((b * a.OH + oy0) * a.OW + ox0) * a.Cout * (unsigned)sizeof(T);
 #pragma unroll
         for (int j = 0; j < NPV; ++j) {
             const bool ok = (unsigned)(oy0 + (pyx[j] >> 16)) < (unsigned)a.IH &&
                             (unsigned)(ox0 - 64 + (pyx[j] & 0xFFFF)) < (unsigned)a.IW;
-            pok |= ok ? (1u << j) : 0u;
-            pv[j] = *reinterpret_cast<const uint4*>(xt + (ok ? prel[j] : -org));
+            pv[j] = buffer_load16(xbuf, ok ? xorg + (unsigned)prel[j] : xbytes);
         }
 #pragma unroll
         for (int j = 0; j < NDV; ++j) {
             const bool ok = oy0 + (drc[j] >> 16) < a.OH && ox0 + (drc[j] & 0xFFFF) < a.OW;
-            dok |= ok ? (1u << j) : 0u;
-            dv[j] = *reinterpret_cast<const uint4*>(dt + (ok ? drel[j] : 0));
+            dv[j] = buffer_load16(dbuf, ok ? dorg + (unsigned)drel[j] : dbytes);
         }
     };
     auto stash = [&]() {
 #pragma unroll
         for (int j = 0; j < NPV; ++j) {
             const int i = tid + j * 256;
-            const unsigned m = (unsigned)(-(int)((pok >> j) & 1u));
-            const uint4 t = make_uint4(pv[j].x & m, pv[j].y & m, pv[j].z & m, pv[j].w & m);
+            const uint4 t = pv[j];   // by value first: a conditional store straight from the array keeps it in scratch
             if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + (i / VPP) * PXB + (i % VPP) * 16) = t;
         }
 #pragma unroll
         for (int j = 0; j < NDV; ++j) {
             const int i = tid + j * 256;
-            const unsigned m = (unsigned)(-(int)((dok >> j) & 1u));
-            const uint4 t = make_uint4(dv[j].x & m, dv[j].y & m, dv[j].z & m, dv[j].w & m);
+            const uint4 t = dv[j];
             if (i < (MTP << dsh)) *reinterpret_cast<uint4*>(dyl + (i >> dsh) * DYB + (i & (dvp - 1)) * 16) = t;
         }
     };
@@ -911,6 +907,11 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
                                  int G, int B, int IH, int IW, int Cin, int Cin_real, int OH, int OW, int Cout,
                                  int pad, int R, int CW) {
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || G < 1) return VQA_ERR_ARG;
+    {   // x and dy are addressed through 32-bit byte offsets (buffer resources)
+        const int esz_ = dtype == VQA_BF16 ? 2 : 4;
+        if ((double)B * IH * IW * Cin * esz_ >= 4294967040.0 || (double)B * OH * OW * Cout * esz_ >= 4294967040.0)
+            return VQA_ERR_ARG;
+    }
     const int tx_ = (OW + CW - 1) / CW, ty_ = (OH + R - 1) / R;
     const int COW = Cout >= 64 ? 64 : Cout;      // output channels per workgroup
     if ((COW != 16 && COW != 32 && COW != 64) || Cout % COW) return VQA_ERR_ARG;

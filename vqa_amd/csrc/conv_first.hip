@@ -28,16 +28,29 @@ struct FirstArgs {
 constexpr int PMAX = 384;                       // host bound on (R+2)*(CW+2)
 constexpr int NIV = (3 * PMAX + 255) / 256;     // image elements per thread per tile
 
-template <typename TI> __device__ __forceinline__ float ld_f32(const TI* p) { return (float)*p; }
+// One image element through the buffer resource: an offset at or beyond the buffer's size returns 0 (the zero padding).
+template <typename TI> __device__ __forceinline__ float buffer_ld_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off);
+template <> __device__ __forceinline__ float buffer_ld_f32<_Float16>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, 0);
+    return (float)__builtin_bit_cast(_Float16, h);
+}
+template <> __device__ __forceinline__ float buffer_ld_f32<bf16>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, 0);
+    return __uint_as_float((unsigned)h << 16);
+}
+template <> __device__ __forceinline__ float buffer_ld_f32<float>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
 
 // Both kernels are persistent: workgroup g walks the (image, tile) pairs t = g, g + G, ...; what does not depend on the
 // tile is computed once per workgroup (a wave64 VALU instruction costs its SIMD 4 cycles, and per-tile index
 // arithmetic is what these HBM-bound kernels spend their time on otherwise).
 struct PatchPlan {           // per thread: the NIV patch elements (c, py, px) it stages
-    int rel[NIV];            // c*IH*IW + (py-pad)*IW + (px-pad): offset from the tile's top-left input pixel
+    int rel[NIV];            // BYTES from the tile's top-left input pixel: (c*IH*IW + (py-pad)*IW + (px-pad)) * sizeof(TI)
     int pyx[NIV];            // (py-pad) << 16 | (px-pad+64); "never inside" rows for elements beyond the patch
 };
 
+template <typename TI>
 __device__ __forceinline__ void plan_patch(const FirstArgs& a, int PW, int PP, PatchPlan& pl) {
     const int tid = threadIdx.x;
     const float inv_pp = 1.0f / PP;
@@ -46,34 +59,32 @@ __device__ __forceinline__ void plan_patch(const FirstArgs& a, int PW, int PP, P
         const int i = tid + j * 256;
         const int c = fastdiv(i, PP, inv_pp), rem = i - c * PP;
         const int py = fastdiv(rem, PW, a.inv_pw), px = rem - py * PW;
-        pl.rel[j] = c * a.IH * a.IW + (py - a.pad) * a.IW + (a.flip ? a.pad - px : px - a.pad);
+        pl.rel[j] = (c * a.IH * a.IW + (py - a.pad) * a.IW + (a.flip ? a.pad - px : px - a.pad)) * (int)sizeof(TI);
         pl.pyx[j] = ((c < 3 ? py - a.pad : -0x4000) << 16) | (px - a.pad + 64);
     }
 }
 
-// Branch-free fetch of tile (b, oy0, ox0): all NIV loads in flight together; out-of-image elements read the image's
-// first element and are zeroed in stash_patch (okbits).
+// Branch-free fetch of tile (b, oy0, ox0): all NIV loads in flight together; out-of-image elements are requested at the
+// buffer's size, which the hardware answers with 0.
 template <typename TI>
-__device__ __forceinline__ void fetch_patch(const FirstArgs& a, const TI* img, const PatchPlan& pl, int b, int oy0,
-                                            int ox0, float (&v)[NIV], unsigned& okbits) {
-    const int org = oy0 * a.IW + (a.flip ? a.IW - 1 - ox0 : ox0);     // (mirrored column: in range iff the column is)
-    const TI* it = img + (long)b * 3 * a.IH * a.IW + org;
-    okbits = 0;
+__device__ __forceinline__ void fetch_patch(const FirstArgs& a, __amdgpu_buffer_rsrc_t ibuf, unsigned ibytes,
+                                            const PatchPlan& pl, int b, int oy0, int ox0, float (&v)[NIV]) {
+    // (mirrored column: in range iff the column is)
+    const unsigned org = (unsigned)((b * 3 * a.IH + oy0) * a.IW + (a.flip ? a.IW - 1 - ox0 : ox0)) * (unsigned)sizeof(TI);
 #pragma unroll
     for (int j = 0; j < NIV; ++j) {
         const bool ok = (unsigned)(oy0 + (pl.pyx[j] >> 16)) < (unsigned)a.IH &&
                         (unsigned)(ox0 - 64 + (pl.pyx[j] & 0xFFFF)) < (unsigned)a.IW;
-        okbits |= ok ? (1u << j) : 0u;
-        v[j] = ld_f32(it + (ok ? pl.rel[j] : -org));
+        v[j] = buffer_ld_f32<TI>(ibuf, ok ? org + (unsigned)pl.rel[j] : ibytes);
     }
 }
 
-__device__ __forceinline__ void stash_patch(unsigned char* patch, int n, const float (&v)[NIV], unsigned okbits) {
+__device__ __forceinline__ void stash_patch(unsigned char* patch, int n, const float (&v)[NIV]) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < NIV; ++j) {
         const int i = tid + j * 256;
-        const bf16 t = (bf16)(((okbits >> j) & 1u) ? v[j] : 0.f);
+        const bf16 t = (bf16)v[j];
         if (i < n) reinterpret_cast<bf16*>(patch)[i] = t;
     }
 }
@@ -92,11 +103,12 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
-    const TI* img = static_cast<const TI*>(a.img);
+    const unsigned ibytes = (unsigned)a.B * 3 * a.IH * a.IW * (unsigned)sizeof(TI);      // (launcher: < 4 GiB)
+    const __amdgpu_buffer_rsrc_t ibuf = buffer_of(a.img, ibytes);
     if ((int)blockIdx.x >= total) return;
 
     PatchPlan pl;
-    plan_patch(a, PW, PP, pl);
+    plan_patch<TI>(a, PW, PP, pl);
     // weight fragment (MFMA A operand: row = output channel r, k = 8q..8q+7), straight from the f32 master
     const float wsc = a.wscale ? a.wscale[r] : 1.f;
     bf16x8 fw;
@@ -126,7 +138,6 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
     const f32x4 bias4 = {bv[0], bv[1], bv[2], bv[3]};
 
     float pv[NIV];
-    unsigned okbits;
     auto tile_org = [&](int t, int& b, int& oy0, int& ox0) {
         b = fastdiv(t, tiles, a.inv_tiles);
         const int tl = t - b * tiles, ty = fastdiv(tl, a.tiles_x, a.inv_tx);
@@ -136,14 +147,14 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
     int fb, foy0, fox0;
     const bool relu = a.relu != 0;
     tile_org(blockIdx.x, fb, foy0, fox0);
-    fetch_patch<TI>(a, img, pl, fb, foy0, fox0, pv, okbits);
+    fetch_patch<TI>(a, ibuf, ibytes, pl, fb, foy0, fox0, pv);
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        stash_patch(smem, 3 * PP, pv, okbits);
+        stash_patch(smem, 3 * PP, pv);
         __syncthreads();
         const int b = fb, oy0 = foy0, ox0 = fox0;
         if (t + (int)gridDim.x < total) {
             tile_org(t + gridDim.x, fb, foy0, fox0);
-            fetch_patch<TI>(a, img, pl, fb, foy0, fox0, pv, okbits);
+            fetch_patch<TI>(a, ibuf, ibytes, pl, fb, foy0, fox0, pv);
         }
         bf16* yt = a.y + ((long)(b * a.OH + oy0) * a.OW + ox0) * 16 + (q >> 1) * 8;
         // Fragments in pairs: after the MFMA a lane holds 4 channels (8 bytes) of one pixel per fragment.  One
@@ -209,20 +220,21 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
     short* ptab = reinterpret_cast<short*>(dyl + MTP * 32);       // [MTP] byte offset of pixel m inside a patch plane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4, rq = r >> 2, p = r & 3;
-    const TI* img = static_cast<const TI*>(a.img);
-    const bf16* dy = a.y;
+    const unsigned ibytes = (unsigned)a.B * 3 * a.IH * a.IW * (unsigned)sizeof(TI);      // (launcher: both < 4 GiB)
+    const unsigned dbytes = (unsigned)a.B * a.OH * a.OW * 32u;
+    const __amdgpu_buffer_rsrc_t ibuf = buffer_of(a.img, ibytes), dbuf = buffer_of(a.y, dbytes);
     const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
     if ((int)blockIdx.x >= total) return;
 
     PatchPlan pl;
-    plan_patch(a, PW, PP, pl);
+    plan_patch<TI>(a, PW, PP, pl);
     // dy vectors of this thread: pixel m = i >> 1, half vv = i & 1
     int drel[2], drc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i = tid + j * 256, m = i >> 1, vv = i & 1;
         const int pr = fastdiv(m, a.CW, a.inv_cw), pc = m - pr * a.CW;
-        drel[j] = (pr * a.OW + pc) * 16 + vv * 8;
+        drel[j] = ((pr * a.OW + pc) * 16 + vv * 8) * 2;          // bytes
         drc[j] = ((m < MT ? pr : 0x4000) << 16) | pc;
     }
     if (tid < MTP) {
@@ -241,28 +253,24 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
     };
     float pv[NIV];
     uint4 dv[2];
-    unsigned okbits, dok = 0;
     auto fetch = [&](int t) {
         int b, oy0, ox0;
         tile_org(t, b, oy0, ox0);
-        fetch_patch<TI>(a, img, pl, b, oy0, ox0, pv, okbits);
-        const bf16* dt = dy + ((long)(b * a.OH + oy0) * a.OW + ox0) * 16;
-        dok = 0;
+        fetch_patch<TI>(a, ibuf, ibytes, pl, b, oy0, ox0, pv);
+        const unsigned dorg = (unsigned)((b * a.OH + oy0) * a.OW + ox0) * 32u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bool ok = oy0 + (drc[j] >> 16) < a.OH && ox0 + (drc[j] & 0xFFFF) < a.OW;
-            dok |= ok ? (1u << j) : 0u;
-            dv[j] = *reinterpret_cast<const uint4*>(dt + (ok ? drel[j] : 0));
+            dv[j] = buffer_load16(dbuf, ok ? dorg + (unsigned)drel[j] : dbytes);
         }
     };
     fetch(blockIdx.x);
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        stash_patch(patch, 3 * PP, pv, okbits);
+        stash_patch(patch, 3 * PP, pv);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = tid + j * 256;
-            const unsigned msk = (unsigned)(-(int)((dok >> j) & 1u));
-            const uint4 tv = make_uint4(dv[j].x & msk, dv[j].y & msk, dv[j].z & msk, dv[j].w & msk);
+            const uint4 tv = dv[j];
             if (i < MTP * 2) *reinterpret_cast<uint4*>(dyl + i * 16) = tv;
         }
         __syncthreads();
@@ -321,6 +329,8 @@ bool first_args(FirstArgs& a, int B, int IH, int IW, int OH, int OW, int pad, in
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || R * CW > 256 ||
         (R + 2) * (CW + 2) > PMAX || B < 1)
         return false;
+    // the kernels address images and y through 32-bit buffer offsets (out-of-range offset = zero padding)
+    if ((size_t)B * 3 * IH * IW * 4 >= (1ull << 32) || (size_t)B * OH * OW * 32 >= (1ull << 32)) return false;
     a.B = B; a.IH = IH; a.IW = IW; a.OH = OH; a.OW = OW; a.pad = pad; a.R = R; a.CW = CW;
     a.tiles_x = (OW + CW - 1) / CW; a.tiles_y = (OH + R - 1) / R;
     a.inv_cw = 1.0f / CW; a.inv_pw = 1.0f / (CW + 2); a.inv_tx = 1.0f / a.tiles_x;

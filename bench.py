@@ -100,12 +100,14 @@ KERNEL_OF = {'vqa_conv3x3_fwd': 'conv3x3_igemm', 'vqa_conv3x3_wgrad': 'conv3x3_w
 
 def roofline_leg(trainer, batch):
     """One extra, instrumented step: HIP events around every C-ABI call on the launching stream (question encoder
-    kept on the main stream for this step, so no launch is timed under a concurrent kernel); picks the device kernel
-    with the largest total time (conv3x3_igemm serves the forward conv AND the data gradient) and prices the sum of
-    its launches against the roofline that binds that sum."""
+    and weight gradients kept on the main stream for this step, so no launch is timed under a concurrent kernel);
+    picks the device kernel with the largest total time (conv3x3_igemm serves the forward conv AND the data gradient)
+    and prices the sum of its launches against the roofline that binds that sum."""
     from vqa_amd import _lib as L
+    from vqa_amd import cnn as CN
     from vqa_amd import vqa_model as VM
     side, VM.SIDE_STREAM = VM.SIDE_STREAM, False
+    wside, CN.WGRAD_STREAM = CN.WGRAD_STREAM, False
     try:
         trainer.step(*batch)
         L.profile_start()
@@ -113,6 +115,7 @@ def roofline_leg(trainer, batch):
         prof = L.profile_stop()
     finally:
         VM.SIDE_STREAM = side
+        CN.WGRAD_STREAM = wside
     totals = {k: sum(ms for ms, _ in v) for k, v in prof.items()}
     rows, fam = {}, {}
     for name, recs in prof.items():

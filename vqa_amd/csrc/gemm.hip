@@ -419,10 +419,14 @@ void launch_bf16(hipStream_t s, const GemmArgs& g, int splits) {
     constexpr int lds = 2 * ((TN ? BK : BM_) * (TN ? BM_ * 2 + 32 : BK * 2 + 32) +
                              (TN ? BK : BN_) * (TN ? BN_ * 2 + 32 : BK * 2 + 32));
     auto k = gemm_bf16<TN, TM, TNT, BK, TC>;
-    static bool attr_set = false;   // benign race: the attribute is idempotent
-    if (lds > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+    if constexpr (lds > 64 * 1024) {
+        static bool attr_set[64] = {};   // per device (the attribute lives on the device's copy of the function);
+        int dev = 0;                     // benign race: setting it twice is idempotent
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
     }
     dim3 grid((g.N + BN_ - 1) / BN_, (g.M + BM_ - 1) / BM_, splits);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, g);

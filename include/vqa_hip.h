@@ -48,9 +48,11 @@ int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked,
 int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW);
 
 /* First encoder layer, bf16 path: nn.Conv2d(3, 16, 3, padding=pad) (cnn.py:23) straight from the NCHW image
- * (in_dtype f16 / f32 / bf16; dataset.py:96-98 stores f16) - no NHWC copy, no channel padding: k = (c, ky, kx) = 27
- * is one 32-deep MFMA.  w is the f32 master weight [16][3][3][3]; y is NHWC bf16 [B][OH][OW][16]; G persistent
- * workgroups (<= tiles * B) walk the tiles, stats = [G][16][2] as in vqa_conv3x3_fwd.
+ * (in_dtype f16 / f32 / bf16; dataset.py:96-98 stores f16) - no NHWC copy, no channel padding.
+ * w is the f32 master weight [16][3][3][3]; y is NHWC bf16 [B][OH][OW][16]; G persistent workgroups (<= tiles * B)
+ * walk the R x CW output tiles, stats = [G][16][2] as in vqa_conv3x3_fwd.
+ * Tile limits: R * CW <= 256; (R+2) * (CW+2) <= 511 for _fwd (wide tiles: its stores want long runs), <= 384 for
+ * _wgrad.  Images < 2 GiB, y / dy < 4 GiB (32-bit buffer offsets).
  * _wgrad: dw [16][3][3][3] f32 from dy (NHWC bf16) and the image; part = [G][16][32] f32.
  * flip != 0 reads every image mirrored along its width: the whole-batch RandomHorizontalFlip of the training loop
  * (vqa_model.py:250, model.flip) without a flipped copy of the batch. */

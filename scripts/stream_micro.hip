@@ -93,6 +93,14 @@ __global__ __launch_bounds__(256) void read2_wg(const v4u* __restrict__ a, const
     }
     if (acc == 0x12345678u) out[0] = v4u{acc, 0, 0, 0};
 }
+// write-only: WG b stores elements [b*256*U, (b+1)*256*U) (what bounds a kernel that mostly writes, e.g. layer 1)
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void write_wg(v4u* __restrict__ out, long n, unsigned seed) {
+    const long i = (long)blockIdx.x * 256 * U + threadIdx.x;
+    const v4u v = {seed, (unsigned)i, seed ^ 0x5555u, 7u};
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (i + u * 256 < n) { if (NT) __builtin_nontemporal_store(v, out + i + u * 256); else out[i + u * 256] = v; }
+}
 __global__ void fill(v4u* p, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v4u{(unsigned)i, (unsigned)(i * 3), (unsigned)(i * 7), 1u};
 }
@@ -136,6 +144,11 @@ int main() {
         float ms = timeit([&] { rot = (rot + 1) % NB; hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, 0, __VA_ARGS__); }); \
         printf("%-22s grid %7d  %.3f ms  %.2f TB/s\n", name, g, ms, (nbytes) / ms * 1e-9);    \
     }
+    RUNWG("write_wg U1", (write_wg<1, false>), 1.0 * bytes, 256, out[rot], n, 1u)
+    RUNWG("write_wg U4", (write_wg<4, false>), 1.0 * bytes, 1024, out[rot], n, 2u)
+    RUNWG("write_wg U8", (write_wg<8, false>), 1.0 * bytes, 2048, out[rot], n, 3u)
+    RUNWG("write_wg U4 nt", (write_wg<4, true>), 1.0 * bytes, 1024, out[rot], n, 4u)
+    RUNWG("write_wg U8 nt", (write_wg<8, true>), 1.0 * bytes, 2048, out[rot], n, 5u)
     RUNWG("copy_wg U1", (copy_wg<1, false>), 2.0 * bytes, 256, in[rot], out[rot], n)
     RUNWG("copy_wg U2", (copy_wg<2, false>), 2.0 * bytes, 512, in[rot], out[rot], n)
     RUNWG("copy_wg U4", (copy_wg<4, false>), 2.0 * bytes, 1024, in[rot], out[rot], n)

@@ -177,12 +177,31 @@ def first_ok(images, w, dtype):
             images.shape[1] == 3 and images.dtype in (torch.float16, torch.float32, torch.bfloat16))
 
 
+@functools.lru_cache(maxsize=None)
+def pick_first_tile(oh, ow):
+    """Output tile (R, CW) of the first-layer forward kernel: R*CW <= 256 pixels, (R+2)*(CW+2) <= 511 patch pixels.
+    The kernel is bound by its stores (32 bytes per output pixel against 6 read), and long contiguous store runs are
+    what the memory system rewards: 226x226 at B=256 runs 0.168 ms with 21x12 tiles, 0.147 with 6x38, 0.137-0.139 with
+    3x76 / 2x113.  Cost = tiles (every tile costs a full 256-pixel pass) x (1 + 24 / CW)."""
+    best = None
+    for r in range(1, min(oh, 256) + 1):
+        cw_max = min(256 // r, 511 // (r + 2) - 2, ow)
+        if cw_max < 1:
+            break
+        nx = -(-ow // cw_max)
+        cw = -(-ow // nx)
+        cost = nx * (-(-oh // r)) * (1.0 + 24.0 / cw)
+        if best is None or cost < best[0]:
+            best = (cost, r, cw)
+    return best[1], best[2]
+
+
 def first_fwd(images, w, bias, pad, want_stats, wscale=None, relu=False, mirror=False):
     B, _, IH, IW = images.shape
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
-    R, CW = pick_tile(OH, OW)
+    R, CW = pick_first_tile(OH, OW)
     y = torch.empty(B, OH, OW, 16, device=images.device, dtype=torch.bfloat16)
-    G = min(B * (-(-OH // R)) * (-(-OW // CW)), 256 * 4)      # persistent workgroups: 4 resident per CU
+    G = min(B * (-(-OH // R)) * (-(-OW // CW)), 256 * 5)      # persistent workgroups: 5 resident per CU (92 VGPRs)
     stats = torch.empty(G, 16, 2, device=images.device, dtype=torch.float32) if want_stats else None
     tag = dict(kind='first', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
                bytes=float(images.numel() * images.element_size() + y.numel() * 2 + w.numel() * 4))
@@ -258,26 +277,32 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
                                         L.ptr(dbeta), L.ptr(c1), L.ptr(c2)), 'vqa_bn_bwd_finalize')
     tag = dict(kind='apply', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((2 * y.numel() + d.numel()) * es))
     L.call('vqa_bn_bwd', L.dt(y), 1, y, d, dy, scale, shift, mean, invstd, c1, c2, None, B, H, W, C, pool, tag=tag)
+    def wgrad():
+        return (first_wgrad(x, dy, pad, out=dw_out, mirror=mirror) if first
+                else conv_wgrad(x, dy, cin_real, pad, out=dw_out))
+
+    def dgrad():
+        if not need_dx:
+            return None
+        wd = wpk_d if wpk_d is not None else pack_weights(w, x.shape[3], x.dtype, dgrad=True)
+        return conv_fwd(dy, wd, None, x.shape[3], 2 - pad, False, kind='dgrad')[0]
+
     if side is None:
-        dw = (first_wgrad(x, dy, pad, out=dw_out, mirror=mirror) if first
-              else conv_wgrad(x, dy, cin_real, pad, out=dw_out))
+        dw = wgrad()
+        dx = dgrad()
     else:
+        # (enqueueing the data gradient first instead measured the same)
         side.wait_event(torch.cuda.current_stream().record_event())
         with torch.cuda.stream(side):
-            dw = (first_wgrad(x, dy, pad, out=dw_out, mirror=mirror) if first
-                  else conv_wgrad(x, dy, cin_real, pad, out=dw_out))
+            dw = wgrad()
         dy.record_stream(side)
         x.record_stream(side)
+        dx = dgrad()
     # the conv bias feeds a training-mode BatchNorm: its gradient is identically zero (the reference produces
     # rounding noise ~1e-7 of the weight-gradient scale here)
     # (its slot in the flat gradient buffer is never written: zero from FlatParams' initial fill)
     if dbias is None:
         dbias = torch.zeros(C, device=dev, dtype=torch.float32)
-    dx = None
-    if need_dx:
-        if wpk_d is None:
-            wpk_d = pack_weights(w, x.shape[3], x.dtype, dgrad=True)
-        dx, _ = conv_fwd(dy, wpk_d, None, x.shape[3], 2 - pad, False, kind='dgrad')
     return dx, dw, dbias, dgamma, dbeta
 
 

@@ -1,12 +1,15 @@
 // First conv layer of the image encoder (reference cnn.py:23, Conv2d(3, 16, 3, padding)), bf16 path.
 // The generic implicit-GEMM kernel needs the 3 image channels padded to one 16-channel MFMA k-group in an NHWC copy
-// (5.3x the image bytes, plus the copy kernel).  Here the whole reduction is k = (c, ky, kx) = 27 <= 32 = ONE
-// v_mfma_f32_16x16x32_bf16 per 16 output pixels, fed straight from the NCHW image (f16 / f32 / bf16, dataset.py:96):
-//   conv3x3_first_fwd    y[B][OH][OW][16] (bf16, NHWC) = conv(images) + bias, with the BatchNorm partial statistics
-//   conv3x3_first_wgrad  dW[16][3][3][3] = sum over pixels of dy (x) image patch, persistent workgroups over tiles
-// LDS image patch: 3 planes of (R+2) x (CW+2) bf16; fragment elements are gathered with 2-byte LDS reads
-// (k-major gather offsets are per-lane constants).  HBM-bound: bytes = |images| + |y|.
+// (5.3x the image bytes, plus the copy kernel).  Here the whole reduction is k = (c, ky, kx) = 27, fed straight from
+// the NCHW image (f16 / f32 / bf16, dataset.py:96):
+//   conv3x3_first_fwd    y[B][OH][OW][16] (bf16, NHWC) = conv(images) + bias, with the BatchNorm partial statistics;
+//                        LDS patch pixel-interleaved (4 bf16 per pixel), three 16x16x16 MFMAs per 16 output pixels
+//   conv3x3_first_wgrad  dW[16][3][3][3] = sum over pixels of dy (x) image patch, persistent workgroups over tiles;
+//                        LDS patch as 3 planes of (R+2) x (CW+2) bf16, fragment elements gathered with 2-byte LDS
+//                        reads (k-major gather offsets are per-lane constants), one 16x16x32 MFMA per 32 pixels
+// HBM-bound: bytes = |images| + |y|.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -96,48 +99,110 @@ __device__ __forceinline__ int gather_off(int k, int PW, int PP) {
     return c * PP + (t / 3) * PW + (t % 3);
 }
 
+// ---- forward: pixel-interleaved patch.  LDS holds the (R+2) x (CW+2) input pixels as 4 bf16 each (3 channels and a
+// zero), 8 bytes per pixel.  The K = 16 values of ONE kernel row ky - k = 4*kx + c with kx, c in 0..3, where kx = 3 and
+// c = 3 carry zero weights - are then the 8 bytes of pixel (pr + ky, pc + q) for lane group q: one ds_read_b64 per
+// kernel row and three chained 16x16x16 MFMAs per fragment, instead of eight 2-byte gathers with their address adds
+// and v_perm packing in front of one 16x16x32 MFMA (the kernel is VALU-bound, not MFMA-bound).  Lane group 3 of the
+// last pixels of a patch row reads one pixel past the row (weight 0): the next row's first pixel, or the spare pixel
+// PP that every stash zeroes.
+constexpr int PMAX_F = 511;                     // forward: host bound on (R+2)*(CW+2) (+ the spare pixel: 512)
+constexpr int NPX = (PMAX_F + 1 + 255) / 256;   // patch pixels per thread per tile
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct PixelPlan {           // per thread: the NPX patch pixels it stages (all three channels of each)
+    int rel[NPX];            // BYTES of channel 0 from the tile's top-left input pixel
+    int pyx[NPX];            // (py-pad) << 16 | (px-pad+64); "never inside" rows for pixels beyond the patch
+};
+
 template <typename TI>
+__device__ __forceinline__ void plan_pixels(const FirstArgs& a, int PW, int PP, PixelPlan& pl) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+        const int i = tid + j * 256;
+        const int py = fastdiv(i, PW, a.inv_pw), px = i - py * PW;
+        pl.rel[j] = ((py - a.pad) * a.IW + (a.flip ? a.pad - px : px - a.pad)) * (int)sizeof(TI);
+        pl.pyx[j] = ((i < PP ? py - a.pad : -0x4000) << 16) | (px - a.pad + 64);
+    }
+}
+
+// all 3*NPX loads of tile (b, oy0, ox0) in flight together; out-of-image pixels are requested at the buffer's size
+// (the launcher keeps the image tensor under 2 GiB, so size + 2 planes cannot wrap)
+template <typename TI>
+__device__ __forceinline__ void fetch_pixels(const FirstArgs& a, __amdgpu_buffer_rsrc_t ibuf, unsigned ibytes,
+                                             unsigned plane, const PixelPlan& pl, int b, int oy0, int ox0,
+                                             float (&v)[NPX][3]) {
+    const unsigned org = (unsigned)((b * 3 * a.IH + oy0) * a.IW + (a.flip ? a.IW - 1 - ox0 : ox0)) * (unsigned)sizeof(TI);
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+        const bool ok = (unsigned)(oy0 + (pl.pyx[j] >> 16)) < (unsigned)a.IH &&
+                        (unsigned)(ox0 - 64 + (pl.pyx[j] & 0xFFFF)) < (unsigned)a.IW;
+        const unsigned o = ok ? org + (unsigned)pl.rel[j] : ibytes;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[j][c] = buffer_ld_f32<TI>(ibuf, o + c * plane);
+    }
+}
+
+__device__ __forceinline__ void stash_pixels(unsigned char* patch, int PP, const float (&v)[NPX][3]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+        const int i = tid + j * 256;
+        const bf16x4 t = {(bf16)v[j][0], (bf16)v[j][1], (bf16)v[j][2], (bf16)0.f};
+        if (i <= PP) *reinterpret_cast<bf16x4*>(patch + i * 8) = t;     // pixel PP: the zeroed spare
+    }
+}
+
+template <typename TI, bool RELU, bool STATS>
 __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int PW = a.CW + 2, PP = (a.R + 2) * PW, MT = a.R * a.CW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
-    const unsigned ibytes = (unsigned)a.B * 3 * a.IH * a.IW * (unsigned)sizeof(TI);      // (launcher: < 4 GiB)
+    const unsigned plane = (unsigned)a.IH * a.IW * (unsigned)sizeof(TI);
+    const unsigned ibytes = (unsigned)a.B * 3 * plane;                                   // (launcher: < 2 GiB)
     const __amdgpu_buffer_rsrc_t ibuf = buffer_of(a.img, ibytes);
     if ((int)blockIdx.x >= total) return;
 
-    PatchPlan pl;
-    plan_patch<TI>(a, PW, PP, pl);
-    // weight fragment (MFMA A operand: row = output channel r, k = 8q..8q+7), straight from the f32 master
+    PixelPlan pl;
+    plan_pixels<TI>(a, PW, PP, pl);
+    // weight fragments (MFMA A operand: row = output channel r, k = 4q + e <-> kx = q, c = e), one per kernel row,
+    // straight from the f32 master
     const float wsc = a.wscale ? a.wscale[r] : 1.f;
-    bf16x8 fw;
+    s16x4 fw[3];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 8 * q + j;
-        const float wk = a.w[r * 27 + (k < 27 ? k : 26)];     // unconditional load, zeroed by the multiply
-        fw[j] = (bf16)(wk * (k < 27 ? wsc : 0.f));
+    for (int ky = 0; ky < 3; ++ky) {
+        bf16x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool live = q < 3 && e < 3;
+            const float wk = a.w[r * 27 + (live ? e * 9 + ky * 3 + q : 0)];   // unconditional load
+            t[e] = (bf16)(live ? wk * wsc : 0.f);
+        }
+        fw[ky] = __builtin_bit_cast(s16x4, t);
     }
-    int koff[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) koff[j] = gather_off(8 * q + j, PW, PP) * 2;
     float bv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) bv[e] = a.bias ? a.bias[q * 4 + e] : 0.f;
     // fragment pixel decode: fragment f of this wave = tile pixels (wave*4+f)*16 + r
-    int pbase[4], frc[4];
+    int paddr[4][3], frc[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
         const int m = (wave * 4 + f) * 16 + r;
         int pr = 0, pc = 0;
         if (m < MT) { pr = fastdiv(m, a.CW, a.inv_cw); pc = m - pr * a.CW; }
-        pbase[f] = (pr * PW + pc) * 2;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) paddr[f][ky] = ((pr + ky) * PW + pc + q) * 8;
         frc[f] = ((m < MT ? pr : 0x4000) << 16) | pc;
     }
+    const unsigned ybytes = (unsigned)a.B * a.OH * a.OW * 32u;                           // (launcher: < 4 GiB)
+    const __amdgpu_buffer_rsrc_t ybuf = buffer_of(a.y, ybytes);
     f32x2 s1[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, s2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
     const f32x4 bias4 = {bv[0], bv[1], bv[2], bv[3]};
 
-    float pv[NIV];
+    float pv[NPX][3];
     auto tile_org = [&](int t, int& b, int& oy0, int& ox0) {
         b = fastdiv(t, tiles, a.inv_tiles);
         const int tl = t - b * tiles, ty = fastdiv(tl, a.tiles_x, a.inv_tx);
@@ -145,18 +210,25 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
         ox0 = (tl - ty * a.tiles_x) * a.CW;
     };
     int fb, foy0, fox0;
-    const bool relu = a.relu != 0;
     tile_org(blockIdx.x, fb, foy0, fox0);
-    fetch_patch<TI>(a, ibuf, ibytes, pl, fb, foy0, fox0, pv);
+    fetch_pixels<TI>(a, ibuf, ibytes, plane, pl, fb, foy0, fox0, pv);
+    // Loads and stores share one counter per wave (s_waitcnt vmcnt) and complete out of order with respect to each
+    // other, so the wait for a tile's pixels is also a wait for every store issued before it.  The stores of tile t
+    // are therefore held in registers and issued after the wait of tile t+1: both the prefetch and the stores get
+    // a whole iteration to complete, instead of the store round trip being exposed in every iteration.
+    uint4 held[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    unsigned hoff[2] = {ybytes, ybytes};                     // (buffer size = dropped)
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        stash_patch(smem, 3 * PP, pv);
+        stash_pixels(smem, PP, pv);
         __syncthreads();
         const int b = fb, oy0 = foy0, ox0 = fox0;
         if (t + (int)gridDim.x < total) {
             tile_org(t + gridDim.x, fb, foy0, fox0);
-            fetch_patch<TI>(a, ibuf, ibytes, pl, fb, foy0, fox0, pv);
+            fetch_pixels<TI>(a, ibuf, ibytes, plane, pl, fb, foy0, fox0, pv);
         }
-        bf16* yt = a.y + ((long)(b * a.OH + oy0) * a.OW + ox0) * 16 + (q >> 1) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) buffer_store16(ybuf, hoff[h], held[h]);     // (first tile: dropped)
+        const unsigned ybase = (unsigned)((b * a.OH + oy0) * a.OW + ox0) * 32u + (q >> 1) * 16;
         // Fragments in pairs: after the MFMA a lane holds 4 channels (8 bytes) of one pixel per fragment.  One
         // v_permlane16_swap per dword between the fragments of a pair leaves every lane with 8 consecutive channels
         // (16 bytes) of ONE pixel - even lane groups the pair's first fragment, odd groups the second - so the tile
@@ -164,32 +236,34 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
 #pragma unroll
         for (int fp2 = 0; fp2 < 2; ++fp2) {
             uint2 pk[2];
-            int orel[2];
+            unsigned orel[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int f = fp2 * 2 + h;
                 const int pr = frc[f] >> 16, pc = frc[f] & 0xFFFF;
                 const bool ok = oy0 + pr < a.OH && ox0 + pc < a.OW;
-                orel[h] = ok ? (pr * a.OW + pc) * 16 : -1;
-                const unsigned char* base = smem + pbase[f];
-                bf16x8 fp;
+                orel[h] = ok ? ybase + (unsigned)(pr * a.OW + pc) * 32u : ybytes;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) fp[j] = *reinterpret_cast<const bf16*>(base + koff[j]);
-                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fp, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                for (int ky = 0; ky < 3; ++ky) {
+                    const s16x4 fp = *reinterpret_cast<const s16x4*>(smem + paddr[f][ky]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fw[ky], fp, acc, 0, 0, 0);
+                }
                 const float okf = ok ? 1.f : 0.f;
-                const Packed4<bf16> o = relu ? epilogue4<bf16, true>(acc, bias4, okf, s1, s2)
-                                             : epilogue4<bf16, false>(acc, bias4, okf, s1, s2);
+                const Packed4<bf16> o = epilogue4<bf16, RELU, STATS>(acc, bias4, okf, s1, s2);
                 pk[h] = make_uint2(o.lo, o.hi);
             }
             auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
             auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
             // lane group q now holds channels (q>>1)*8 .. +7 of the pixel of fragment (q&1) of the pair
-            const int op = (q & 1) ? orel[1] : orel[0];
-            if (op >= 0) *reinterpret_cast<uint4*>(yt + op) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            hoff[fp2] = (q & 1) ? orel[1] : orel[0];
+            held[fp2] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
         }
         __syncthreads();                                      // fragment reads done before the next stash
     }
-    if (a.stats) {                                            // one row of partial sums per workgroup
+#pragma unroll
+    for (int h = 0; h < 2; ++h) buffer_store16(ybuf, hoff[h], held[h]);
+    if (STATS) {                                              // one row of partial sums per workgroup
         float* red = reinterpret_cast<float*>(smem);          // [4 waves][16][2]
         float t1[4] = {s1[0].x, s1[0].y, s1[1].x, s1[1].y}, t2[4] = {s2[0].x, s2[0].y, s2[1].x, s2[1].y};
         sum16_x4(t1[0], t1[1], t1[2], t1[3]);
@@ -325,12 +399,12 @@ __global__ __launch_bounds__(256) void first_wgrad_reduce(const float* part, flo
     if (lane == 0) dw[o] = s;
 }
 
-bool first_args(FirstArgs& a, int B, int IH, int IW, int OH, int OW, int pad, int R, int CW) {
+bool first_args(FirstArgs& a, int B, int IH, int IW, int OH, int OW, int pad, int R, int CW, int pmax) {
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || R * CW > 256 ||
-        (R + 2) * (CW + 2) > PMAX || B < 1)
+        (R + 2) * (CW + 2) > pmax || B < 1)
         return false;
     // the kernels address images and y through 32-bit buffer offsets (out-of-range offset = zero padding)
-    if ((size_t)B * 3 * IH * IW * 4 >= (1ull << 32) || (size_t)B * OH * OW * 32 >= (1ull << 32)) return false;
+    if ((size_t)B * 3 * IH * IW * 4 >= (1ull << 31) || (size_t)B * OH * OW * 32 >= (1ull << 32)) return false;
     a.B = B; a.IH = IH; a.IW = IW; a.OH = OH; a.OW = OW; a.pad = pad; a.R = R; a.CW = CW;
     a.tiles_x = (OW + CW - 1) / CW; a.tiles_y = (OH + R - 1) / R;
     a.inv_cw = 1.0f / CW; a.inv_pw = 1.0f / (CW + 2); a.inv_tx = 1.0f / a.tiles_x;
@@ -347,16 +421,23 @@ extern "C" int vqa_conv3x3_first_fwd(void* stream, int in_dtype, const void* ima
     a.wscale = wscale;
     a.relu = relu;
     a.flip = flip;
-    if (!images || !w || !y || !first_args(a, B, IH, IW, OH, OW, pad, R, CW)) return VQA_ERR_ARG;
+    if (!images || !w || !y || !first_args(a, B, IH, IW, OH, OW, pad, R, CW, PMAX_F)) return VQA_ERR_ARG;
     if (G < 1 || G > a.tiles_x * a.tiles_y * B) return VQA_ERR_ARG;
-    size_t lds = (size_t)3 * (R + 2) * (CW + 2) * 2;
+    size_t lds = (size_t)((R + 2) * (CW + 2) + 1) * 8;       // the patch pixels and the spare one, 8 bytes each
     if (lds < 512) lds = 512;
     dim3 grid(G);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (in_dtype == VQA_F16) hipLaunchKernelGGL(conv3x3_first_fwd<_Float16>, grid, dim3(256), lds, s, a);
-    else if (in_dtype == VQA_F32) hipLaunchKernelGGL(conv3x3_first_fwd<float>, grid, dim3(256), lds, s, a);
-    else if (in_dtype == VQA_BF16) hipLaunchKernelGGL(conv3x3_first_fwd<bf16>, grid, dim3(256), lds, s, a);
-    else return VQA_ERR_ARG;
+    if (in_dtype != VQA_F16 && in_dtype != VQA_F32 && in_dtype != VQA_BF16) return VQA_ERR_ARG;
+    auto go = [&](auto relu_tag, auto stats_tag) {
+        constexpr bool RL = decltype(relu_tag)::value, ST = decltype(stats_tag)::value;
+        if (in_dtype == VQA_F16) hipLaunchKernelGGL((conv3x3_first_fwd<_Float16, RL, ST>), grid, dim3(256), lds, s, a);
+        else if (in_dtype == VQA_F32) hipLaunchKernelGGL((conv3x3_first_fwd<float, RL, ST>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((conv3x3_first_fwd<bf16, RL, ST>), grid, dim3(256), lds, s, a);
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (relu) { if (stats) go(T_{}, T_{}); else go(T_{}, F_{}); }
+    else { if (stats) go(F_{}, T_{}); else go(F_{}, F_{}); }
     CHECK_LAUNCH();
     return VQA_OK;
 }
@@ -368,7 +449,7 @@ extern "C" int vqa_conv3x3_first_wgrad(void* stream, int in_dtype, const void* i
     a.wscale = nullptr;
     a.relu = 0;
     a.flip = flip;
-    if (!images || !dy || !part || !dw || G < 1 || !first_args(a, B, IH, IW, OH, OW, pad, R, CW)) return VQA_ERR_ARG;
+    if (!images || !dy || !part || !dw || G < 1 || !first_args(a, B, IH, IW, OH, OW, pad, R, CW, PMAX)) return VQA_ERR_ARG;
     const int MTP = (R * CW + 31) / 32 * 32;
     if (G > a.tiles_x * a.tiles_y * B) return VQA_ERR_ARG;
     size_t lds = (size_t)(3 * (R + 2) * (CW + 2) * 2 + 15) / 16 * 16 + (size_t)MTP * 32 + (size_t)MTP * 2;

@@ -145,7 +145,7 @@ def roofline_leg(trainer, batch):
     out['per_launch'] = [f"{name}[{tag['kind']}] {tag['shape']:>18s} {ms:7.3f} ms {tag['flops'] / ms / 1e9:8.1f} TF/s "
                          f"{tag['bytes'] / ms / 1e6:8.1f} GB/s"
                          for name, recs in prof.items() for ms, tag in recs if tag]
-    breakdown = {k: round(v['ms'], 3) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]['ms'])[:14]}
+    breakdown = {k: round(v['ms'], 3) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:48]}
     return out, breakdown, sum(totals.values())
 
 

@@ -34,6 +34,17 @@ def test_pick_tile_covers_and_fits():
             assert -(-oh // r) * r >= oh and -(-ow // cw) * cw >= ow
 
 
+def test_pick_first_tile_fits_the_kernel_limits():
+    # include/vqa_hip.h: R*CW <= 256; (R+2)*(CW+2) <= 511 (first-layer forward) / 384 (first-layer weight gradient)
+    from vqa_amd.cnn import pick_first_tile
+    for oh, ow in [(226, 226), (224, 224), (222, 222), (450, 450), (448, 448), (458, 458), (114, 114), (53, 53),
+                   (12, 12), (7, 300), (300, 7), (1, 1), (2, 1000), (1000, 2)]:
+        for pm in (511, 384):
+            r, cw = pick_first_tile(oh, ow, pm)
+            assert 1 <= r <= oh and 1 <= cw <= ow and r * cw <= 256 and (r + 2) * (cw + 2) <= pm
+    assert pick_first_tile(226, 226)[1] >= 76          # long store runs where the image allows them
+
+
 def test_vocab_and_text_helpers(tmp_path):
     """build_vocab restates legacy torchtext.vocab.Vocab ordering (reference gru.py:39); the text helpers follow
     gru.py:55-68 and :87-99."""

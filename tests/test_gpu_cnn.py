@@ -54,7 +54,8 @@ def test_conv_fwd_dgrad_wgrad_exact(prec, B, cin, cout, H, W, pad):
 
 
 @pytest.mark.parametrize('img_dtype', [torch.float16, torch.float32])
-@pytest.mark.parametrize('B,H,W,pad', [(2, 20, 20, 2), (3, 13, 37, 0), (1, 70, 226, 2), (2, 33, 18, 5), (2, 9, 9, 1)])
+@pytest.mark.parametrize('B,H,W,pad', [(2, 20, 20, 2), (3, 13, 37, 0), (1, 70, 226, 2), (2, 33, 18, 5), (2, 9, 9, 1),
+                                       (1, 5, 300, 0), (1, 300, 6, 1)])
 def test_first_layer_exact(img_dtype, B, H, W, pad):
     """Dedicated Conv2d(3, 16) kernels on the NCHW image: small-integer data, bit-exact forward, statistics and
     weight gradient (the generic kernels on the channel-padded NHWC copy are the second witness)."""

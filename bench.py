@@ -166,6 +166,9 @@ def main():
                     help="NOT the headline: every step's batch starts in pinned host memory (the reference's loop does "
                          "batch['image'].to(device), vqa_model.py:250-252).  'sync' copies on the compute stream, "
                          "'overlap' copies the next batch on a second stream while the current step runs")
+    ap.add_argument('--serial-streams', action='store_true',
+                    help='NOT the headline: question encoder and weight gradients on the main stream for the whole run '
+                         '(for rocprofv3 --kernel-trace: per-kernel durations without a concurrent kernel)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='also print the per-kernel time table to stderr')
     args = ap.parse_args()
@@ -185,6 +188,10 @@ def main():
     from vqa_amd import synth
     from vqa_amd.optim import Trainer
     import vqa_model
+    if args.serial_streams:
+        from vqa_amd import cnn as CN
+        from vqa_amd import vqa_model as VM
+        VM.SIDE_STREAM = CN.WGRAD_STREAM = False
 
     classes, vocab = 3129, 10000
     with tempfile.TemporaryDirectory() as tmp:

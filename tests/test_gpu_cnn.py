@@ -94,13 +94,14 @@ def test_first_layer_exact(img_dtype, B, H, W, pad):
 @pytest.mark.parametrize('prec,tol', [('fp32', 1e-5), ('bf16', 2e-2)])
 @pytest.mark.parametrize('pool', [0, 1, 2])
 @pytest.mark.parametrize('C', [16, 64, 256])
-def test_bn_relu_pool_fwd_bwd(prec, tol, pool, C):
+@pytest.mark.parametrize('H,W', [(10, 12), (11, 13), (2, 3)])
+def test_bn_relu_pool_fwd_bwd(prec, tol, pool, C, H, W):
     from vqa_amd import _lib as L, cnn as M
     from oracle import vqa_oracle as O
     import ctypes
     torch.manual_seed(C + pool)
     dt = DT[prec]
-    B, H, W = 3, 10, 12
+    B = 3
     y = (torch.randn(B, C, H, W) * 1.5 + 0.3).to(dt).float()
     gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.3
     yr = y.clone().requires_grad_(True)

@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd(const T* __restrict__ y, 
 // vector takes its 2x2 window from there.  In bn_act_pool_fwd<POOL != 0> each load instruction picks the even or the
 // odd pixels of a row - half of every line it touches.  224x224x16: 0.103 -> 0.086 ms (6.0 TB/s), 112x112x32: 0.053 ->
 // 0.040.  (The same staging for the backward reduce pass measured slower: its workgroups loop over several rows to
-// keep the number of partial-sum rows down, and the barriers of that loop cost more than the access pattern gains.)
+// keep the number of partial-sum rows down, and the barriers of that loop cost more than the access pattern gains; for
+// the backward apply pass, load -> barrier -> dy in place -> barrier -> store per row pair: 224x224x16 0.168 -> 0.189.)
 template <typename T, int POOL, bool NT>
 __global__ __launch_bounds__(256) void bn_pool_rows_fwd(const T* __restrict__ y, T* __restrict__ a,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,

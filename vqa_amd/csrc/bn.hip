@@ -14,6 +14,31 @@ namespace {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
+// Sums of the two columns (c, 0) and (c, 1) of part[rows][C][2] over the rows, fp64, fixed order; 256 threads; the
+// result is valid in thread 0.  Four rows per thread are in flight at a time.
+__device__ __forceinline__ void column_sums(const float* part, int rows, int C, int c, double& s1, double& s2) {
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i0 = threadIdx.x; i0 < rows; i0 += 4 * 256) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256;
+            v[u] = i < rows ? *reinterpret_cast<const float2*>(part + ((long)i * C + c) * 2) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a1[u] += (double)v[u].x; a2[u] += (double)v[u].y; }
+    }
+    s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+    __shared__ double r1[4], r2[4];
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    s1 = r1[0] + r1[1] + r1[2] + r1[3];
+    s2 = r2[0] + r2[1] + r2[2] + r2[3];
+}
+
 // One workgroup per channel: sums the conv epilogue's partial rows (a few hundred to a few thousand: one per
 // persistent conv workgroup) in fp64 in a fixed order, then produces the BN coefficients and running statistics.
 __global__ __launch_bounds__(256) void bn_finalize(const float* part, int rows, int C, double count,
@@ -21,32 +46,28 @@ __global__ __launch_bounds__(256) void bn_finalize(const float* part, int rows, 
                                                    float* running_var, float momentum, float eps, float* mean,
                                                    float* invstd, float* scale, float* shift) {
     const int c = blockIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = threadIdx.x; i < rows; i += blockDim.x) {
-        const float2 v = *reinterpret_cast<const float2*>(part + ((long)i * C + c) * 2);
-        s1 += (double)v.x;
-        s2 += (double)v.y;
+    // (this kernel sits between every conv and its BatchNorm pass: the parameter loads are issued first and the rows
+    // are read four at a time, so the whole kernel is two memory round trips instead of rows/256 + 2)
+    float ga = 0.f, be = 0.f, rm = 0.f, rv = 0.f;
+    if (threadIdx.x == 0) {
+        ga = gamma[c]; be = beta[c];
+        if (running_mean) { rm = running_mean[c]; rv = running_var[c]; }
     }
-    __shared__ double r1[4], r2[4];
-    s1 = wave_sum_d(s1);
-    s2 = wave_sum_d(s2);
-    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
-    __syncthreads();
+    double s1, s2;
+    column_sums(part, rows, C, c, s1, s2);
     if (threadIdx.x != 0) return;
-    s1 = r1[0] + r1[1] + r1[2] + r1[3];
-    s2 = r2[0] + r2[1] + r2[2] + r2[3];
     const double m = s1 / count;
     double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = (float)m;
     invstd[c] = is;
-    const float sc = gamma[c] * is;
+    const float sc = ga * is;
     scale[c] = sc;
-    shift[c] = beta[c] - (float)m * sc;
+    shift[c] = be - (float)m * sc;
     if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * count / (count - 1.0));
+        running_mean[c] = (1.f - momentum) * rm + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * rv + momentum * (float)(var * count / (count - 1.0));
     }
 }
 
@@ -355,19 +376,9 @@ __global__ __launch_bounds__(256) void bn_bwd(const T* __restrict__ y, const T* 
 __global__ void bn_bwd_finalize(const float* part, int rows, int C, double count, float* dgamma, float* dbeta,
                                 float* c1, float* c2) {
     const int c = blockIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = threadIdx.x; i < rows; i += blockDim.x) {
-        s1 += (double)part[((long)i * C + c) * 2];
-        s2 += (double)part[((long)i * C + c) * 2 + 1];
-    }
-    __shared__ double r1[4], r2[4];
-    s1 = wave_sum_d(s1);
-    s2 = wave_sum_d(s2);
-    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
-    __syncthreads();
+    double s1, s2;
+    column_sums(part, rows, C, c, s1, s2);
     if (threadIdx.x == 0) {
-        s1 = r1[0] + r1[1] + r1[2] + r1[3];
-        s2 = r2[0] + r2[1] + r2[2] + r2[3];
         dbeta[c] = (float)s1;
         dgamma[c] = (float)s2;
         c1[c] = (float)(s1 / count);

@@ -107,6 +107,7 @@ def roofline_leg(trainer, batch):
     from vqa_amd import cnn as CN
     from vqa_amd import vqa_model as VM
     side, VM.SIDE_STREAM = VM.SIDE_STREAM, False
+    hside, VM.HEAD_WGRAD_STREAM = VM.HEAD_WGRAD_STREAM, False
     wside, CN.WGRAD_STREAM = CN.WGRAD_STREAM, False
     try:
         trainer.step(*batch)
@@ -114,7 +115,7 @@ def roofline_leg(trainer, batch):
         trainer.step(*batch)
         prof = L.profile_stop()
     finally:
-        VM.SIDE_STREAM = side
+        VM.SIDE_STREAM, VM.HEAD_WGRAD_STREAM = side, hside
         CN.WGRAD_STREAM = wside
     totals = {k: sum(ms for ms, _ in v) for k, v in prof.items()}
     rows, fam = {}, {}
@@ -191,7 +192,7 @@ def main():
     if args.serial_streams:
         from vqa_amd import cnn as CN
         from vqa_amd import vqa_model as VM
-        VM.SIDE_STREAM = CN.WGRAD_STREAM = False
+        VM.SIDE_STREAM = VM.HEAD_WGRAD_STREAM = CN.WGRAD_STREAM = False
 
     classes, vocab = 3129, 10000
     with tempfile.TemporaryDirectory() as tmp:

@@ -65,6 +65,32 @@ def grad_dst(p):
     return d.view(p.shape)
 
 
+# ---- work deferred to a side stream inside a backward (head / conv weight gradients): whoever reads its results on
+# another stream joins first - the end-of-backward callback below, the data-parallel bucket hooks, Trainer.step.
+_deferred = []
+
+
+def defer_reset():
+    """Start of a backward that may defer work: forget the events of the previous pass."""
+    del _deferred[:]
+
+
+def defer_join(side):
+    """Call at the end of side-stream work issued from inside a backward: records its completion and arranges for the
+    stream that called .backward() to wait for it before backward() returns (autograd runs its final callbacks on
+    that stream)."""
+    _deferred.append(side.record_event())
+    torch.autograd.Variable._execution_engine.queue_callback(join_deferred)
+
+
+def join_deferred():
+    """Make the current stream wait for the side-stream work deferred in this backward pass (idempotent)."""
+    if _deferred:
+        cur = torch.cuda.current_stream()
+        for ev in _deferred:
+            cur.wait_event(ev)
+
+
 def dot(a, b):
     out = torch.empty(1, device=a.device, dtype=torch.float32)
     L.check(L.lib().vqa_dot(L.stream(), L.ptr(a), L.ptr(b), ctypes.c_long(a.numel()), L.ptr(scratch(a.device)),

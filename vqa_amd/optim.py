@@ -108,6 +108,7 @@ class GradBuckets:
         def hook(_p):
             self._left[b] -= 1
             if self._left[b] == 0:
+                ops.join_deferred()     # gradients a backward left running on a side stream (head weight gradients)
                 self.flat.collect([q for q, bq in zip(self.flat.params, self._bucket_idx) if bq == b])
                 s, e = self.flat.bucket_ranges[b]
                 self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
@@ -165,6 +166,7 @@ class Trainer:
         logits = self.model(images, questions, mirror=mirror)
         loss = self.criterion(logits, target)
         loss.backward()
+        ops.join_deferred()
         if not self.buckets.active:
             self.flat.collect()
         self.buckets.wait()

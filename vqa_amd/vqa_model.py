@@ -70,6 +70,10 @@ HEAD_LAYERS = ['linear_inside_relu_attention', 'linear_after_relu_attention', 'l
                'linear_inside_relu_question', 'linear_inside_relu_last', 'fc']
 
 
+# Head parameter gradients on the weight-gradient stream (see _HeadFunction.backward); VQA_HEAD_WGRAD_STREAM=0: inline
+HEAD_WGRAD_STREAM = os.environ.get('VQA_HEAD_WGRAD_STREAM', '1') != '0'
+
+
 class _HeadFunction(torch.autograd.Function):
     """(v [B,k,D] fp32, q [B,H] fp32, weights) -> logits [B,C] fp32."""
 
@@ -122,41 +126,58 @@ class _HeadFunction(torch.autograd.Function):
         dtype, dev = ctx.dtype, dlogits.device
         new = lambda *s, dt=dtype: torch.empty(*s, device=dev, dtype=dt)
 
+        ops.defer_reset()
+        # ---- data path first: what the image and question encoders wait for
         dl_t = ops.cast_pad(dlogits.contiguous(), dtype, ops.pad8(C))            # [B,C] (padded rows)
-        dW_fc = ops.gemm(dl_t, m_t, trans=True)                                  # [C,H]
         dm = ops.gemm(dl_t, W_fc_T)                                              # [B,H]
         dpre_last = new(B, H)
         L.call('vqa_relu_bwd', L.dt(dpre_last), dm, m, mask2, B * H, dpre_last)
-        dW_last = ops.gemm(dpre_last, m0, trans=True)
-        db_last = ops.colsum(dpre_last, out=ops.grad_dst(b_last))
         dm0 = ops.gemm(dpre_last, W_last_T)
         dpv, dpq = new(B, H), new(B, H)
         L.call('vqa_hadamard_bwd', L.dt(dpv), dm0, fv, fq, mask1, B * H, dpv, dpq)
-        dW_img = ops.gemm(dpv, vhat_t, trans=True)                               # [H,D]
-        db_img = ops.colsum(dpv, out=ops.grad_dst(b_img))
         dvhat = ops.gemm(dpv, W_img_T)                                           # [B,D]
-        dW_q = ops.gemm(dpq, q_t, trans=True)
-        db_q = ops.colsum(dpq, out=ops.grad_dst(b_q))
         dq = ops.gemm(dpq, W_q_T)                                                # [B,H]
-        # attention
         dv = new(B * K, D, dt=torch.float32)
         dpre_a = new(B * K, H)
         dws_part = new(B, H, dt=torch.float32)
         L.call('vqa_attn_bwd', L.dt(a), a, w_s, v, p, dvhat, B, K, H, D, dv, dpre_a, dws_part)
-        dW_s = ops.colsum(dws_part).reshape(1, H)
         ops.gemm(dpre_a, W_att_T[:D], out=dv, accumulate=True)                   # += dpre_a @ W_v
         dqa, dqa_t = new(B, H, dt=torch.float32), new(B, H)
         L.call('vqa_group_sum', L.dt(dpre_a), dpre_a, B, K, H, dqa, dqa_t)
-        db_att = ops.colsum(dqa, out=ops.grad_dst(b_att))
-        dW_att = new(H, D + H, dt=torch.float32)
-        ops.gemm(dpre_a, v_t, trans=True, out=dW_att[:, :D])
-        ops.gemm(dqa_t, q_t, trans=True, out=dW_att[:, D:])
         ops.gemm(dqa_t, W_att_T[D:], out=dq, accumulate=True)                    # += dqa @ W_q-part
-        # weight-norm backward
-        ((dg_att, dv_att), (dg_s, dv_s), (dg_img, dv_img), (dg_q, dv_q), (dg_last, dv_last),
-         (dg_fc, dv_fc)) = ops.weight_norm_bwd_all([(dW_att, v_att, g_att), (dW_s, v_s, g_s), (dW_img, v_img, g_img),
-                                                    (dW_q, v_q, g_q), (dW_last, v_last, g_last), (dW_fc, v_fc, g_fc)],
-                                                   ss)
+
+        # ---- parameter gradients: nothing downstream in this backward needs them, so they run on the weight-gradient
+        # stream beside the encoders' backward (ops.defer_join: joined before backward() returns / before a bucket
+        # all-reduce reads them)
+        def weights():
+            dW_fc = ops.gemm(dl_t, m_t, trans=True)                              # [C,H]
+            dW_last = ops.gemm(dpre_last, m0, trans=True)
+            db_last = ops.colsum(dpre_last, out=ops.grad_dst(b_last))
+            dW_img = ops.gemm(dpv, vhat_t, trans=True)                           # [H,D]
+            db_img = ops.colsum(dpv, out=ops.grad_dst(b_img))
+            dW_q = ops.gemm(dpq, q_t, trans=True)
+            db_q = ops.colsum(dpq, out=ops.grad_dst(b_q))
+            dW_s = ops.colsum(dws_part).reshape(1, H)
+            db_att = ops.colsum(dqa, out=ops.grad_dst(b_att))
+            dW_att = new(H, D + H, dt=torch.float32)
+            ops.gemm(dpre_a, v_t, trans=True, out=dW_att[:, :D])
+            ops.gemm(dqa_t, q_t, trans=True, out=dW_att[:, D:])
+            wn = ops.weight_norm_bwd_all([(dW_att, v_att, g_att), (dW_s, v_s, g_s), (dW_img, v_img, g_img),
+                                          (dW_q, v_q, g_q), (dW_last, v_last, g_last), (dW_fc, v_fc, g_fc)], ss)
+            return wn, db_att, db_img, db_q, db_last
+
+        if HEAD_WGRAD_STREAM:
+            from .cnn import _wgrad_stream
+            side = _wgrad_stream(dev)
+            side.wait_event(torch.cuda.current_stream().record_event())
+            with torch.cuda.stream(side):
+                wn, db_att, db_img, db_q, db_last = weights()
+            for t in (dl_t, m_t, dpre_last, m0, dpv, vhat_t, dpq, q_t, dws_part, dqa, dpre_a, v_t, dqa_t, ss):
+                t.record_stream(side)                                            # (freed on this stream, read on that)
+            ops.defer_join(side)
+        else:
+            wn, db_att, db_img, db_q, db_last = weights()
+        (dg_att, dv_att), (dg_s, dv_s), (dg_img, dv_img), (dg_q, dv_q), (dg_last, dv_last), (dg_fc, dv_fc) = wn
         return (dv.reshape(B, K, D), dq, None, None, dg_att, dv_att, db_att, dg_s, dv_s, dg_img, dv_img, db_img, dg_q,
                 dv_q, db_q, dg_last, dv_last, db_last, dg_fc, dv_fc)
 

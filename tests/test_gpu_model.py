@@ -267,3 +267,31 @@ def test_mirror_equals_flipped_batch(prec, tmp_path):
             assert torch.allclose(out[0][1][k], out[1][1][k], rtol=1e-5, atol=1e-7)
         else:
             assert torch.equal(out[0][1][k], out[1][1][k]), k
+
+
+@pytest.mark.parametrize('prec', ['bf16', 'fp32'])
+def test_side_streams_do_not_change_results(prec, tmp_path, monkeypatch):
+    """Question encoder, conv weight gradients and head parameter gradients on their side streams (the default) against
+    everything on the caller's stream: logits and every gradient bit for bit, read right after backward() returns
+    (plain loss.backward(), no Trainer: the end-of-backward callback of ops.defer_join is what joins the streams)."""
+    import vqa_model
+    from vqa_amd import cnn as CN, vqa_model as VM
+    c = load_case('h64_p5_max')
+    img, q, t = c['images'].cuda(), c['questions'].cuda(), c['targets'].cuda()
+    out = []
+    for streams in (True, False):
+        monkeypatch.setattr(VM, 'SIDE_STREAM', streams)
+        monkeypatch.setattr(VM, 'HEAD_WGRAD_STREAM', streams)
+        monkeypatch.setattr(CN, 'WGRAD_STREAM', streams)
+        m = build_model(c, tmp_path, prec).cuda().train()
+        for _ in range(3):                                       # repeated: a missed join shows as a stale gradient
+            m.zero_grad(set_to_none=True)
+            logits = m(img, q)
+            vqa_model.SoftScoreBCELoss()(logits, t).backward()
+        out.append((logits.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+    assert torch.equal(out[0][0], out[1][0])
+    for k in out[0][1]:
+        if k == 'gru.word_embedding.weight':                 # float atomics in the scatter-add
+            assert torch.allclose(out[0][1][k], out[1][1][k], rtol=1e-5, atol=1e-7)
+        else:
+            assert torch.equal(out[0][1][k], out[1][1][k]), k

@@ -597,16 +597,26 @@ __global__ void sum_f32(const float* x, int n, float* out) {
 
 // ---------------------------------------------------------------------------------------- clip + Adamax
 // coef = min(1, max_norm / (sqrt(sqsum) + 1e-6))      (nn.utils.clip_grad_norm_)
-__global__ void clip_coef(const float* sqsum, float max_norm, float* coef, float* total_norm) {
-    const float n = sqrtf(sqsum[0]);
-    total_norm[0] = n;
-    const float c = max_norm / (n + 1e-6f);
-    coef[0] = c < 1.f ? c : 1.f;
-}
 // torch.optim.Adamax, weight_decay 0:  m = b1 m + (1-b1) g ; u = max(b2 u, |g| + eps) ; p -= lr/(1-b1^t) m/u
-__global__ void adamax_step(float* p, const float* g, float* m, float* u, long n, const float* coef, float lr_t,
-                            float b1, float b2, float eps) {
-    const float c = coef ? coef[0] : 1.f;
+// part != null: the clip coefficient is computed here, by every workgroup alike, from the 1024 partial sums of
+// |g|^2 (fixed order -> the same value everywhere); workgroup 0 publishes sq / coef / total_norm.  Two launches
+// (final sum, coefficient) less at the end of every step.
+__global__ __launch_bounds__(256) void adamax_step(float* p, const float* g, float* m, float* u, long n,
+                                                   const double* part, float max_norm, float* sq, float* coef,
+                                                   float* total_norm, float lr_t, float b1, float b2, float eps) {
+    float c = 1.f;
+    if (part) {
+        __shared__ double r[4];
+        double s = (part[threadIdx.x] + part[threadIdx.x + 256]) + (part[threadIdx.x + 512] + part[threadIdx.x + 768]);
+        s = wave_sum_d(s);
+        if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = s;
+        __syncthreads();
+        const float sqsum = (float)(r[0] + r[1] + r[2] + r[3]);
+        const float nrm = sqrtf(sqsum);
+        const float cc = max_norm / (nrm + 1e-6f);
+        c = cc < 1.f ? cc : 1.f;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { sq[0] = sqsum; coef[0] = c; total_norm[0] = nrm; }
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gv = g[i] * c;
         const float mv = b1 * m[i] + (1.f - b1) * gv;
@@ -874,15 +884,14 @@ extern "C" int vqa_clip_adamax(void* stream, float* p, const float* g, float* m,
                                float lr, float b1, float b2, float eps, int step, double* part, float* sq,
                                float* coef, float* total_norm) {
     if (n <= 0 || step < 1) return VQA_ERR_ARG;
-    const float* cp = nullptr;
+    const double* pp = nullptr;
     if (max_norm > 0.f) {
         hipLaunchKernelGGL(dot_partial, dim3(1024), dim3(256), 0, ST, g, g, n, part);
-        hipLaunchKernelGGL(dot_final, dim3(1), dim3(64), 0, ST, part, 1024, sq);
-        hipLaunchKernelGGL(clip_coef, dim3(1), dim3(1), 0, ST, sq, max_norm, coef, total_norm);
-        cp = coef;
+        pp = part;
     }
     const float lr_t = lr / (1.f - powf(b1, (float)step));
-    hipLaunchKernelGGL(adamax_step, dim3(grid1d(n)), dim3(256), 0, ST, p, g, m, u, n, cp, lr_t, b1, b2, eps);
+    hipLaunchKernelGGL(adamax_step, dim3(grid1d(n)), dim3(256), 0, ST, p, g, m, u, n, pp, max_norm, sq, coef,
+                       total_norm, lr_t, b1, b2, eps);
     CHECK_LAUNCH();
     return VQA_OK;
 }

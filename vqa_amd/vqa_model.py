@@ -103,9 +103,12 @@ class _HeadFunction(torch.autograd.Function):
         fq = ops.gemm(q_t, W_q, bias=b_q, act=1)
         m0 = torch.empty(B, H, device=dev, dtype=dtype)
         L.call('vqa_hadamard_fwd', L.dt(m0), fv, fq, mask1, B * H, m0)
-        m = ops.gemm(m0, W_last, bias=b_last, act=1)
         m_t = torch.empty(B, H, device=dev, dtype=dtype)
-        L.call('vqa_mask_mul', L.dt(m_t), m, mask2, B * H, m_t)
+        if mask2 is None and dtype == torch.bfloat16:
+            m = ops.gemm(m0, W_last, bias=b_last, act=1, c2=m_t)      # no dropout: the GEMM writes the bf16 copy itself
+        else:
+            m = ops.gemm(m0, W_last, bias=b_last, act=1)
+            L.call('vqa_mask_mul', L.dt(m_t), m, mask2, B * H, m_t)
         logits = ops.gemm(m_t, W_fc)
         ctx.save_for_backward(v, q_t, v_t, a, w_s, p, vhat_t, fv, fq, m0, m, m_t, W_att_T, W_img_T, W_q_T, W_last_T,
                               W_fc_T, ss, g_att, v_att, g_s, v_s, g_img, v_img,

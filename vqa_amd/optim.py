@@ -9,6 +9,7 @@
                  :218, :266) as one HIP pass over the flat buffers with no host synchronisation.
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -147,6 +148,10 @@ class FlatAdamax:
                                         L.ptr(self.coef), L.ptr(self.total_norm)), 'vqa_clip_adamax')
 
 
+STEP_PRIORITY = os.environ.get('VQA_STEP_PRIORITY', '1') != '0'
+_STEP_STREAMS = {}
+
+
 class Trainer:
     """One reference training step (vqa_model.py:248-266) on the HIP path:
     zero_grad -> flip -> forward -> sum-BCE -> backward (-> bucketed all-reduce) -> clip 0.25 -> Adamax."""
@@ -160,6 +165,34 @@ class Trainer:
         self.criterion = SoftScoreBCELoss()
 
     def step(self, images, questions, target, flip=True):
+        """The step runs on a high-priority HIP stream of its own, ordered after and before the caller's current
+        stream: its kernels are the critical chain, and the work the model puts on side streams (question encoder,
+        weight gradients: normal priority) then only fills what that chain leaves idle (4.96 -> 4.90 ms/step)."""
+        if not STEP_PRIORITY or not images.is_cuda:
+            return self._step(images, questions, target, flip)
+        cur = torch.cuda.current_stream(images.device)
+        hp = self.stream
+        if cur == hp:                                  # the caller already runs its loop on the trainer's stream
+            return self._step(images, questions, target, flip)
+        hp.wait_stream(cur)
+        with torch.cuda.stream(hp):
+            loss = self._step(images, questions, target, flip)
+        cur.wait_stream(hp)
+        loss.record_stream(cur)
+        return loss
+
+    @property
+    def stream(self):
+        """The trainer's high-priority stream.  A training loop that runs under `with torch.cuda.stream(trainer.stream)`
+        (after `trainer.stream.wait_stream(torch.cuda.current_stream())` for tensors made elsewhere) saves the two
+        cross-stream hand-overs per step that step() otherwise makes to keep the caller's stream semantics."""
+        dev = self.flat.flat.device
+        key = str(dev)
+        if key not in _STEP_STREAMS:
+            _STEP_STREAMS[key] = torch.cuda.Stream(dev, priority=-1)
+        return _STEP_STREAMS[key]
+
+    def _step(self, images, questions, target, flip=True):
         self.opt.zero_grad()
         # the reference flips the batch tensor (vqa_model.py:250); same coin, but the first conv reads it mirrored
         mirror = flip and self.model.flip.draw()

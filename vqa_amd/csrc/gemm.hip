@@ -172,7 +172,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 //   NT LDS row = one m (n), BK k's:      BK*2 + 32 bytes -> 10 / 18 sixteen-byte slots (== 2 mod 4: conflict-free b128)
 //   TN LDS row = one k, BM (BN) m's:     BM*2 + 32 bytes -> 32 * odd (conflict-free transposing reads)
 // TN k map of a 32-k chunk: lane group q, element 4h+e  <->  k = 16h + 4q + e  (same for both operands).
-template <bool TN, int TM, int TNT, int BK, typename TC>
+// NPRE > 1 (small-M problems: a few hundred workgroups, each a short chain of stages): the loads of NPRE stages are
+// issued into registers at once and consumed stage by stage - one memory latency per NPRE stages instead of one per
+// stage, which is what a 256 x 1024 x 1024 GEMM spends its 13 us on.
+template <bool TN, int TM, int TNT, int BK, typename TC, int NPRE = 1>
 __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
     constexpr int BM_ = 32 * TM, BN_ = 32 * TNT;
     constexpr int RA = TN ? BM_ * 2 + 32 : BK * 2 + 32, RB = TN ? BN_ * 2 + 32 : BK * 2 + 32;
@@ -198,8 +201,7 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
     const int kbeg = g.ws ? blockIdx.z * g.kper : 0;
     const int kend = g.ws ? (kbeg + g.kper < g.K ? kbeg + g.kper : g.K) : g.K;
 
-    uint4 ra[NVA], rb[NVB];
-    auto fetch = [&](int k0) {
+    auto fetch_to = [&](int k0, uint4 (&ra)[NVA], uint4 (&rb)[NVB]) {
 #pragma unroll
         for (int j = 0; j < NVA; ++j) {
             const int i = tid + j * 256, row = i / VPA, sl = i % VPA;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
                        : load_row_chunk<bf16>(B, n0 + row, g.ldb, k0 + sl * 8, kend, n0 + row < g.N);
         }
     };
-    auto stash = [&](int buf) {
+    auto stash_from = [&](int buf, const uint4 (&ra)[NVA], const uint4 (&rb)[NVB]) {
         unsigned char* As = dl + buf * (SZA + SZB);
         unsigned char* Bs = As + SZA;
 #pragma unroll
@@ -227,14 +229,7 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
             *reinterpret_cast<uint4*>(Bs + (i / VPB) * RB + (i % VPB) * 16) = rb[j];
         }
     };
-
-    fetch(kbeg);
-    stash(0);
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK, buf ^= 1) {
-        const bool more = k0 + BK < kend;
-        if (more) fetch(k0 + BK);
+    auto compute = [&](int buf) {
         const unsigned char* As = dl + buf * (SZA + SZB);
         const unsigned char* Bs = As + SZA;
 #pragma unroll
@@ -274,8 +269,39 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < TNT; ++j) Mma<bf16>::mma(acc[i][j], fb[j], fa[i]);  // D rows = n, D cols = m
         }
-        if (more) stash(buf ^ 1);
+    };
+    if constexpr (NPRE == 1) {
+        uint4 ra[NVA], rb[NVB];
+        fetch_to(kbeg, ra, rb);
+        stash_from(0, ra, rb);
         __syncthreads();
+        int buf = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += BK, buf ^= 1) {
+            const bool more = k0 + BK < kend;
+            if (more) fetch_to(k0 + BK, ra, rb);
+            compute(buf);
+            if (more) stash_from(buf ^ 1, ra, rb);
+            __syncthreads();
+        }
+    } else {
+        uint4 pa[NPRE][NVA], pb[NPRE][NVB];
+        int buf = 0;
+        for (int kr = kbeg; kr < kend; kr += NPRE * BK) {
+#pragma unroll
+            for (int st = 0; st < NPRE; ++st)
+                if (kr + st * BK < kend) fetch_to(kr + st * BK, pa[st], pb[st]);     // (uniform)
+#pragma unroll
+            for (int st = 0; st < NPRE; ++st) {
+                if (kr + st * BK < kend) {
+                    // buffer `buf` was last read two stages ago; every wave has passed a barrier since
+                    stash_from(buf, pa[st], pb[st]);
+                    __syncthreads();
+                    compute(buf);
+                    buf ^= 1;
+                }
+            }
+        }
+        __syncthreads();                                  // the epilogue reuses the staging LDS
     }
 
     if (g.ws) {
@@ -413,12 +439,12 @@ __global__ void gemm_splitk_reduce(GemmArgs g, int splits) {
     }
 }
 
-template <bool TN, int TM, int TNT, int BK, typename TC>
+template <bool TN, int TM, int TNT, int BK, typename TC, int NPRE = 1>
 void launch_bf16(hipStream_t s, const GemmArgs& g, int splits) {
     constexpr int BM_ = 32 * TM, BN_ = 32 * TNT;
     constexpr int lds = 2 * ((TN ? BK : BM_) * (TN ? BM_ * 2 + 32 : BK * 2 + 32) +
                              (TN ? BK : BN_) * (TN ? BN_ * 2 + 32 : BK * 2 + 32));
-    auto k = gemm_bf16<TN, TM, TNT, BK, TC>;
+    auto k = gemm_bf16<TN, TM, TNT, BK, TC, NPRE>;
     if constexpr (lds > 64 * 1024) {
         static bool attr_set[64] = {};   // per device (the attribute lives on the device's copy of the function);
         int dev = 0;                     // benign race: setting it twice is idempotent
@@ -437,7 +463,11 @@ int launch(hipStream_t s, int trans, const GemmArgs& g, int splits) {
     if constexpr (sizeof(T) == 2) {
         // 128x128 tiles once they alone fill most of the chip, 64x64 (with the caller's split-K) otherwise
         const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-        if (splits == 1 && big >= 160) {
+        // small-M NT problems (the head's and the GRU's M = 256 GEMMs): 32x32 tiles, eight stages of loads in flight
+        const long small = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
+        if (!trans && splits == 1 && small <= 256 && g.K <= 1024) {   // (one workgroup per CU, one round of loads)
+            launch_bf16<false, 1, 1, 128, TC, 8>(s, g, splits);
+        } else if (splits == 1 && big >= 160) {
             if (trans) launch_bf16<true, 4, 4, 64, TC>(s, g, splits);
             else launch_bf16<false, 4, 4, 64, TC>(s, g, splits);
         } else {

@@ -31,6 +31,8 @@ def gemm(A, B, trans=False, M=None, N=None, K=None, out=None, out_dtype=torch.fl
     # split-K when the 64x64 output grid alone cannot fill 256 CUs (2 workgroups each) and the reduction is long;
     # thresholds from scripts/gemm_micro.py + rocprofv3 on the step's shapes
     blocks = -(-M // 64) * -(-N // 64)
+    if splits is None and not trans and A.dtype == torch.bfloat16 and -(-M // 32) * -(-N // 32) <= 256 and K <= 1024:
+        splits = 1            # gemm.hip: 32x32 tiles with eight stages of loads in flight, no split-K pass
     if splits is None:
         if blocks >= 160:
             splits = 2 if (K >= 3072 and blocks < 384) else 1

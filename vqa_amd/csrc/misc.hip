@@ -503,18 +503,33 @@ __global__ void mask_mul(const float* x, const float* mask, long n, T* out) {
 
 // ---------------------------------------------------------------------------------------- loss / accuracy
 // loss = sum max(x,0) - x t + log1p(exp(-|x|)) ; dx = sigmoid(x) - t     (logits [B][C] with row stride ldx)
-__global__ void bce_partial(const float* x, const float* t, int B, int C, int ldx, float* dx, double* part) {
+// (between the head's forward and backward: four elements per thread and round are loaded before any is used - a round
+// trip per round, not per element - and the index arithmetic is 32-bit; the entry checks B*C < 2^31)
+__global__ __launch_bounds__(256) void bce_partial(const float* __restrict__ x, const float* __restrict__ t, int B, int C,
+                                                   int ldx, float* __restrict__ dx, double* part) {
     double s = 0.0;
-    const long total = (long)B * C;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = i % C;
-        const long b = i / C;
-        const float xv = x[b * ldx + c], tv = t[i];
-        const float e = __expf(-fabsf(xv));
-        s += (double)(fmaxf(xv, 0.f) - xv * tv + log1pf(e));
-        if (dx) {
-            const float sg = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-            dx[i] = sg - tv;
+    const int total = B * C, nth = gridDim.x * 256;
+    for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * nth) {
+        float xv[4], tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * nth;
+            const int ic = i < total ? i : total - 1;
+            const int b = ic / C, c = ic - b * C;
+            xv[u] = x[(long)b * ldx + c];
+            tv[u] = t[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * nth;
+            if (i < total) {
+                const float e = __expf(-fabsf(xv[u]));
+                s += (double)(fmaxf(xv[u], 0.f) - xv[u] * tv[u] + log1pf(e));
+                if (dx) {
+                    const float sg = xv[u] >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+                    dx[i] = sg - tv[u];
+                }
+            }
         }
     }
     __shared__ double r[4];
@@ -844,6 +859,7 @@ extern "C" int vqa_mask_mul(void* stream, int dtype, const float* x, const float
 // loss[0] = BCE-with-logits sum; dlogits (may be null) = sigmoid(x) - t.   part: 256 doubles of scratch
 extern "C" int vqa_bce_sum(void* stream, const float* logits, const float* target, int B, int C, int ldx,
                            float* dlogits, double* part, float* loss) {
+    if (B < 1 || C < 1 || (long)B * C >= (1L << 31)) return VQA_ERR_ARG;
     hipLaunchKernelGGL(bce_partial, dim3(256), dim3(256), 0, ST, logits, target, B, C, ldx, dlogits, part);
     hipLaunchKernelGGL(dot_final, dim3(1), dim3(64), 0, ST, part, 256, loss);
     CHECK_LAUNCH();

@@ -458,6 +458,36 @@ __global__ __launch_bounds__(256) void attn_bwd(const T* __restrict__ a, const T
     }
 }
 // out[b][:] = sum_k x[b*K + k][:]
+// The same with one 16-byte channel vector per thread and five rows in flight per round (the scalar form below read
+// K rows of 2 bytes one after the other: K dependent round trips); rows are added in the same order k = 0 .. K-1.
+template <typename T>
+__global__ __launch_bounds__(256) void group_sum_vec(const T* __restrict__ x, int B, int K, int H, float* __restrict__ out,
+                                                     T* __restrict__ out_t) {
+    constexpr int N = Vec16<T>::N, U = 5;
+    const int HV = H / N;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * HV) return;
+    const int b = i / HV, jv = i - b * HV;
+    const T* base = x + ((long)b * K) * H + jv * N;
+    float s[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) s[e] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += U) {
+        float v[U][N];
+#pragma unroll
+        for (int u = 0; u < U; ++u) Vec16<T>::load(base + (long)(k0 + u < K ? k0 + u : K - 1) * H, v[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k0 + u < K) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) s[e] += v[u][e];
+            }
+    }
+    float* o = out + (long)b * H + jv * N;
+#pragma unroll
+    for (int e = 0; e < N; e += 4) *reinterpret_cast<float4*>(o + e) = make_float4(s[e], s[e + 1], s[e + 2], s[e + 3]);
+    Vec16<T>::store(out_t + (long)b * H + jv * N, s);
+}
 template <typename T>
 __global__ void group_sum(const T* x, int B, int K, int H, float* out, T* out_t) {
     const long total = (long)B * H;
@@ -814,6 +844,16 @@ extern "C" int vqa_attn_bwd(void* stream, int dtype, const void* a, const void* 
 }
 
 extern "C" int vqa_group_sum(void* stream, int dtype, const void* x, int B, int K, int H, float* out, void* out_t) {
+    const int N = dtype == VQA_BF16 ? 8 : 4;
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
+                      reinterpret_cast<uintptr_t>(out_t)) & 15) == 0;
+    if (B >= 1 && K >= 1 && H % N == 0 && al && (long)B * (H / N) < (1L << 31)) {
+        const dim3 vgrid((unsigned)(((long)B * (H / N) + 255) / 256));
+        BY_T(dtype, hipLaunchKernelGGL(group_sum_vec<bf16>, vgrid, dim3(256), 0, ST, (const bf16*)x, B, K, H, out, (bf16*)out_t),
+             hipLaunchKernelGGL(group_sum_vec<float>, vgrid, dim3(256), 0, ST, (const float*)x, B, K, H, out, (float*)out_t));
+        CHECK_LAUNCH();
+        return VQA_OK;
+    }
     dim3 grid(grid1d((long)B * H));
     BY_T(dtype, hipLaunchKernelGGL(group_sum<bf16>, grid, dim3(256), 0, ST, (const bf16*)x, B, K, H, out, (bf16*)out_t),
          hipLaunchKernelGGL(group_sum<float>, grid, dim3(256), 0, ST, (const float*)x, B, K, H, out, (float*)out_t));

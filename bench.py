@@ -257,7 +257,7 @@ def main():
                 state['i'] += 1
                 return out
     from vqa_amd import optim as _optim
-    if args.mode == 'train' and args.host_inputs == 'off' and _optim.STEP_PRIORITY:
+    if args.mode == 'train' and _optim.STEP_PRIORITY:
         # the loop runs on the trainer's own high-priority stream (Trainer.stream: no per-step hand-over to the default
         # stream); the batch was made on the default stream
         trainer.stream.wait_stream(torch.cuda.current_stream())

@@ -61,6 +61,14 @@ int vqa_conv3x3_first_fwd(void* stream, int in_dtype, const void* images, const 
                           const float* wscale /* NULL or [16]: folded into w */, int relu, int flip);
 int vqa_conv3x3_first_wgrad(void* stream, int in_dtype, const void* images, const void* dy, float* part, float* dw,
                             int G, int B, int IH, int IW, int OH, int OW, int pad, int R, int CW, int flip);
+/* The same with the BatchNorm-backward apply pass of layer 1 (vqa_bn_bwd, apply = 1, pool = 0) folded in: y is the
+ * layer's raw conv output, g the gradient w.r.t. its BatchNorm + ReLU output (both NHWC bf16 [B][OH][OW][16]) and
+ * scale .. c2 the six [16] coefficient vectors of that pass; dy = scale * ((z > 0 ? g : 0) - c1 - xhat * c2) is formed
+ * at the LDS write and never stored (layer 1 has no data gradient: nobody else reads it). */
+int vqa_conv3x3_first_wgrad_bn(void* stream, int in_dtype, const void* images, const void* y, const void* g,
+                               const float* scale, const float* shift, const float* mean, const float* invstd,
+                               const float* c1, const float* c2, float* part, float* dw, int G, int B, int IH, int IW,
+                               int OH, int OW, int pad, int R, int CW, int flip);
 
 /* Conv2d weight gradient (autograd of cnn.py:23-40): dw [Cout][Cin_real][3][3] f32 = sum over pixels of dy (x) x.
  * `part` is a [G][Cout][9][Cin] f32 workspace (one partial slab per workgroup group, summed in fixed order). */

@@ -91,6 +91,28 @@ def test_first_layer_exact(img_dtype, B, H, W, pad):
     assert torch.equal(C.first_wgrad(img, dyd, pad, mirror=True), C.first_wgrad(imgf, dyd, pad))
 
 
+@pytest.mark.parametrize('B,H,W,pad', [(2, 20, 20, 2), (3, 13, 37, 0), (1, 70, 226, 2), (2, 33, 18, 5), (1, 5, 300, 0)])
+def test_first_layer_fused_bn_wgrad(B, H, W, pad):
+    """vqa_conv3x3_first_wgrad_bn (BatchNorm-backward apply inside the weight gradient, dy never stored) against the
+    two-kernel path vqa_bn_bwd(apply) -> vqa_conv3x3_first_wgrad on the same inputs, mirrored read included.  The fused
+    kernel regroups the affine terms (scale*dz - (A*y + Bc)), so dy may differ by a bf16 rounding here and there."""
+    from vqa_amd import _lib as L, cnn as C
+    torch.manual_seed(B + H + W + pad)
+    OH, OW = H + 2 * pad - 2, W + 2 * pad - 2
+    img = torch.rand(B, 3, H, W).half().cuda()
+    y = (torch.randn(B, OH, OW, 16) * 1.5 + 0.2).bfloat16().cuda()
+    g = torch.randn(B, OH, OW, 16).bfloat16().cuda()
+    scale, shift = (torch.rand(16) + 0.5).cuda(), (torch.randn(16) * 0.3).cuda()
+    mean, invstd = (torch.randn(16) * 0.2).cuda(), (torch.rand(16) + 0.5).cuda()
+    c1, c2 = (torch.randn(16) * 0.05).cuda(), (torch.randn(16) * 0.05).cuda()
+    dy = torch.empty_like(y)
+    L.call('vqa_bn_bwd', L.dt(y), 1, y, g, dy, scale, shift, mean, invstd, c1, c2, None, B, OH, OW, 16, 0)
+    for mirror in (False, True):
+        ref = C.first_wgrad(img, dy, pad, mirror=mirror)
+        got = C.first_wgrad(img, y, pad, mirror=mirror, bn=(g, scale, shift, mean, invstd, c1, c2))
+        assert float((got - ref).norm() / ref.norm()) < 2e-3
+
+
 @pytest.mark.parametrize('prec,tol', [('fp32', 1e-5), ('bf16', 2e-2)])
 @pytest.mark.parametrize('pool', [0, 1, 2])
 @pytest.mark.parametrize('C', [16, 64, 256])

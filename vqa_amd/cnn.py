@@ -211,7 +211,9 @@ def first_fwd(images, w, bias, pad, want_stats, wscale=None, relu=False, mirror=
     return y, stats
 
 
-def first_wgrad(images, dy, pad, out=None, mirror=False):
+def first_wgrad(images, dy, pad, out=None, mirror=False, bn=None):
+    """bn = (g, scale, shift, mean, invstd, c1, c2): `dy` is then the layer's raw conv output y and the BatchNorm-
+    backward apply pass runs inside the kernel (vqa_conv3x3_first_wgrad_bn)."""
     B, _, IH, IW = images.shape
     _, OH, OW, _ = dy.shape
     R, CW = pick_first_tile(OH, OW, 384)                      # (wide tiles: long runs of dy; 0.155 -> 0.139 ms)
@@ -221,6 +223,11 @@ def first_wgrad(images, dy, pad, out=None, mirror=False):
     dw = out if out is not None else torch.empty(16, 3, 3, 3, device=dy.device, dtype=torch.float32)
     tag = dict(kind='first_wgrad', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
                bytes=float(images.numel() * images.element_size() + dy.numel() * 2))
+    if bn is not None:
+        tag['bytes'] += dy.numel() * 2
+        L.call('vqa_conv3x3_first_wgrad_bn', L.dt(images), images, dy, *bn, part, dw, G, B, IH, IW, OH, OW, pad, R, CW,
+               int(mirror), tag=tag)
+        return dw
     L.call('vqa_conv3x3_first_wgrad', L.dt(images), images, dy, part, dw, G, B, IH, IW, OH, OW, pad, R, CW,
            int(mirror), tag=tag)
     return dw
@@ -269,13 +276,27 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
     if dbeta is None:
         dbeta = torch.empty(C, device=dev, dtype=torch.float32)
     c1, c2 = torch.empty(2, C, device=dev, dtype=torch.float32).unbind(0)
-    dy = torch.empty_like(y)
     es = y.element_size()
     tag = dict(kind='reduce', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((y.numel() + d.numel()) * es))
     L.call('vqa_bn_bwd', L.dt(y), 0, y, d, None, scale, shift, mean, invstd, None, None, part, B, H, W, C, pool,
            tag=tag)
     L.check(L.lib().vqa_bn_bwd_finalize(L.stream(), L.ptr(part), rows, C, L.ctypes.c_double(count), L.ptr(dgamma),
                                         L.ptr(dbeta), L.ptr(c1), L.ptr(c2)), 'vqa_bn_bwd_finalize')
+    if first and pool == 0 and not need_dx and FUSE_FIRST_BN:
+        # layer 1: nobody but its weight gradient reads dy - the apply pass runs inside that kernel, dy is never stored
+        bn = (d.contiguous(), scale, shift, mean, invstd, c1, c2)
+        if side is None:
+            dw = first_wgrad(x, y, pad, out=dw_out, mirror=mirror, bn=bn)
+        else:
+            side.wait_event(torch.cuda.current_stream().record_event())
+            with torch.cuda.stream(side):
+                dw = first_wgrad(x, y, pad, out=dw_out, mirror=mirror, bn=bn)
+            for t in (x, y, bn[0], scale, c1, part):
+                t.record_stream(side)
+        if dbias is None:
+            dbias = torch.zeros(C, device=dev, dtype=torch.float32)
+        return None, dw, dbias, dgamma, dbeta
+    dy = torch.empty_like(y)
     tag = dict(kind='apply', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((2 * y.numel() + d.numel()) * es))
     L.call('vqa_bn_bwd', L.dt(y), 1, y, d, dy, scale, shift, mean, invstd, c1, c2, None, B, H, W, C, pool, tag=tag)
     def wgrad():
@@ -351,6 +372,7 @@ def _eval_forward(x, first, params, buffers, padding, pool_mode, dtype):
 # BatchNorm-backward): it runs on its own HIP stream beside the dgrad that reads the same dy (same-box A/B:
 # 5.26 -> 5.22 ms/step).  VQA_WGRAD_STREAM=0 keeps everything on one stream.
 WGRAD_STREAM = os.environ.get('VQA_WGRAD_STREAM', '1') != '0'
+FUSE_FIRST_BN = os.environ.get('VQA_FUSE_FIRST_BN', '1') != '0'
 _WGRAD_STREAMS = {}
 
 

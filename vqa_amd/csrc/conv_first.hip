@@ -26,6 +26,10 @@ struct FirstArgs {
     int relu;            // fwd: y = max(conv + bias, 0)
     int flip;            // read every image mirrored along its width: the reference's whole-batch RandomHorizontalFlip
                          // (vqa_model.py:250) costs nothing here - only the sign of the patch's x step changes
+    // fused wgrad: y = the layer's raw conv output, g = gradient w.r.t. the BatchNorm + ReLU output, and the BatchNorm
+    // backward coefficients [16] each (bn.hip: dy = scale * (dz - c1 - xhat * c2), dz = z > 0 ? g : 0)
+    const bf16* g;
+    const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd, *bn_c1, *bn_c2;
 };
 
 constexpr int PMAX = 384;                       // host bound on (R+2)*(CW+2)
@@ -284,7 +288,9 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
 // (dy fragment by the transposing LDS read), D cols = k index (two 16-column tiles cover k = 0..31), MFMA K = 32
 // pixels with the k <-> pixel map of conv.hip's wgrad: lane group q, element 4h+e <-> pixel ks + 16h + 4q + e.
 // The pixel -> patch offset of every K element is a per-workgroup LDS table (no division in the loop).
-template <typename TI>
+// FUSED: the BatchNorm-backward apply pass of layer 1 happens here, at the LDS write of the dy tile - layer 1 has no data
+// gradient, so its dy was written (418 MB at B = 256) only to be read back by this kernel.
+template <typename TI, bool FUSED>
 __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int PW = a.CW + 2, PP = (a.R + 2) * PW, MT = a.R * a.CW;
@@ -292,13 +298,23 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
     unsigned char* patch = smem;
     unsigned char* dyl = smem + (3 * PP * 2 + 15) / 16 * 16;      // [MTP pixels][16 co] bf16, 32 bytes per pixel
     short* ptab = reinterpret_cast<short*>(dyl + MTP * 32);       // [MTP] byte offset of pixel m inside a patch plane
+    float* coef = reinterpret_cast<float*>(dyl + MTP * 32 + ((MTP * 2 + 15) / 16) * 16);   // FUSED: [4][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4, rq = r >> 2, p = r & 3;
     const unsigned ibytes = (unsigned)a.B * 3 * a.IH * a.IW * (unsigned)sizeof(TI);      // (launcher: both < 4 GiB)
     const unsigned dbytes = (unsigned)a.B * a.OH * a.OW * 32u;
     const __amdgpu_buffer_rsrc_t ibuf = buffer_of(a.img, ibytes), dbuf = buffer_of(a.y, dbytes);
+    const __amdgpu_buffer_rsrc_t gbuf = buffer_of(FUSED ? a.g : a.y, dbytes);
     const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
     if ((int)blockIdx.x >= total) return;
+    if (FUSED && tid < 16) {
+        // dy = scale * (dz - c1 - (y - mean) * invstd * c2)  =  scale * dz - (A * y + Bc),  dz = z > 0 ? g : 0
+        const float sc = a.bn_scale[tid], A = sc * a.bn_invstd[tid] * a.bn_c2[tid];
+        coef[tid] = sc;
+        coef[16 + tid] = a.bn_shift[tid];
+        coef[32 + tid] = A;
+        coef[48 + tid] = sc * a.bn_c1[tid] - A * a.bn_mean[tid];
+    }
 
     PatchPlan pl;
     plan_patch<TI>(a, PW, PP, pl);
@@ -326,25 +342,54 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
         ox0 = (tl - ty * a.tiles_x) * a.CW;
     };
     float pv[NIV];
-    uint4 dv[2];
+    uint4 dv[2], gv[2];
+    unsigned okbits = 0;
     auto fetch = [&](int t) {
         int b, oy0, ox0;
         tile_org(t, b, oy0, ox0);
         fetch_patch<TI>(a, ibuf, ibytes, pl, b, oy0, ox0, pv);
         const unsigned dorg = (unsigned)((b * a.OH + oy0) * a.OW + ox0) * 32u;
+        okbits = 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bool ok = oy0 + (drc[j] >> 16) < a.OH && ox0 + (drc[j] & 0xFFFF) < a.OW;
             dv[j] = buffer_load16(dbuf, ok ? dorg + (unsigned)drel[j] : dbytes);
+            if (FUSED) {
+                gv[j] = buffer_load16(gbuf, ok ? dorg + (unsigned)drel[j] : dbytes);
+                okbits |= ok ? 1u << j : 0u;
+            }
         }
     };
+    // FUSED: (y, g) -> dy of 8 channels (thread's half vv = tid & 1) in packed f32x2 arithmetic; the coefficients are
+    // read from LDS (the kernel has no registers to spare for 32 of them)
+    auto bn_apply = [&](const uint4& yv, const uint4& gq, bool ok) {
+        const unsigned yw[4] = {yv.x, yv.y, yv.z, yv.w}, gw[4] = {gq.x, gq.y, gq.z, gq.w};
+        const f32x2* c2v = reinterpret_cast<const f32x2*>(coef + (tid & 1) * 8);
+        unsigned ow[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const f32x2 y = {__uint_as_float(yw[h] << 16), __uint_as_float(yw[h] & 0xFFFF0000u)};
+            const f32x2 g = {__uint_as_float(gw[h] << 16), __uint_as_float(gw[h] & 0xFFFF0000u)};
+            const f32x2 sc = c2v[h], sh = c2v[8 + h], A = c2v[16 + h], Bc = c2v[24 + h];
+            const f32x2 z = __builtin_elementwise_fma(y, sc, sh);
+            const f32x2 t = sc * g;
+            const f32x2 lin = __builtin_elementwise_fma(A, y, Bc);
+            f32x2 o = {(z.x > 0.f ? t.x : 0.f), (z.y > 0.f ? t.y : 0.f)};
+            o = o - lin;
+            typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bf16x2_t ob = {(bf16)o.x, (bf16)o.y};
+            ow[h] = ok ? __builtin_bit_cast(unsigned, ob) : 0u;
+        }
+        return make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    };
     fetch(blockIdx.x);
+    __syncthreads();                                              // (coef)
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         stash_patch(patch, 3 * PP, pv);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = tid + j * 256;
-            const uint4 tv = dv[j];
+            const uint4 tv = FUSED ? bn_apply(dv[j], gv[j], (okbits >> j) & 1) : dv[j];
             if (i < MTP * 2) *reinterpret_cast<uint4*>(dyl + i * 16) = tv;
         }
         __syncthreads();
@@ -442,6 +487,29 @@ extern "C" int vqa_conv3x3_first_fwd(void* stream, int in_dtype, const void* ima
     return VQA_OK;
 }
 
+static int first_wgrad_launch(void* stream, int in_dtype, FirstArgs& a, float* part, float* dw, int G, int B, int IH,
+                              int IW, int OH, int OW, int pad, int R, int CW, bool fused) {
+    if (!a.img || !a.y || !part || !dw || G < 1 || !first_args(a, B, IH, IW, OH, OW, pad, R, CW, PMAX)) return VQA_ERR_ARG;
+    const int MTP = (R * CW + 31) / 32 * 32;
+    if (G > a.tiles_x * a.tiles_y * B) return VQA_ERR_ARG;
+    size_t lds = (size_t)(3 * (R + 2) * (CW + 2) * 2 + 15) / 16 * 16 + (size_t)MTP * 32 + (size_t)(MTP * 2 + 15) / 16 * 16 +
+                 6 * 16 * 4;
+    if (lds < 3 * 2 * 64 * 16) lds = 3 * 2 * 64 * 16;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (in_dtype != VQA_F16 && in_dtype != VQA_F32 && in_dtype != VQA_BF16) return VQA_ERR_ARG;
+#define GO(F)                                                                                                         \
+    do {                                                                                                              \
+        if (in_dtype == VQA_F16) hipLaunchKernelGGL((conv3x3_first_wgrad<_Float16, F>), dim3(G), dim3(256), lds, s, a); \
+        else if (in_dtype == VQA_F32) hipLaunchKernelGGL((conv3x3_first_wgrad<float, F>), dim3(G), dim3(256), lds, s, a); \
+        else hipLaunchKernelGGL((conv3x3_first_wgrad<bf16, F>), dim3(G), dim3(256), lds, s, a);                        \
+    } while (0)
+    if (fused) GO(true); else GO(false);
+#undef GO
+    hipLaunchKernelGGL(first_wgrad_reduce, dim3(108), dim3(256), 0, s, part, dw, G);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
 extern "C" int vqa_conv3x3_first_wgrad(void* stream, int in_dtype, const void* images, const void* dy, float* part,
                                        float* dw, int G, int B, int IH, int IW, int OH, int OW, int pad, int R,
                                        int CW, int flip) {
@@ -449,17 +517,21 @@ extern "C" int vqa_conv3x3_first_wgrad(void* stream, int in_dtype, const void* i
     a.wscale = nullptr;
     a.relu = 0;
     a.flip = flip;
-    if (!images || !dy || !part || !dw || G < 1 || !first_args(a, B, IH, IW, OH, OW, pad, R, CW, PMAX)) return VQA_ERR_ARG;
-    const int MTP = (R * CW + 31) / 32 * 32;
-    if (G > a.tiles_x * a.tiles_y * B) return VQA_ERR_ARG;
-    size_t lds = (size_t)(3 * (R + 2) * (CW + 2) * 2 + 15) / 16 * 16 + (size_t)MTP * 32 + (size_t)MTP * 2;
-    if (lds < 3 * 2 * 64 * 16) lds = 3 * 2 * 64 * 16;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (in_dtype == VQA_F16) hipLaunchKernelGGL(conv3x3_first_wgrad<_Float16>, dim3(G), dim3(256), lds, s, a);
-    else if (in_dtype == VQA_F32) hipLaunchKernelGGL(conv3x3_first_wgrad<float>, dim3(G), dim3(256), lds, s, a);
-    else if (in_dtype == VQA_BF16) hipLaunchKernelGGL(conv3x3_first_wgrad<bf16>, dim3(G), dim3(256), lds, s, a);
-    else return VQA_ERR_ARG;
-    hipLaunchKernelGGL(first_wgrad_reduce, dim3(108), dim3(256), 0, s, part, dw, G);
-    CHECK_LAUNCH();
-    return VQA_OK;
+    a.g = nullptr;
+    return first_wgrad_launch(stream, in_dtype, a, part, dw, G, B, IH, IW, OH, OW, pad, R, CW, false);
+}
+
+extern "C" int vqa_conv3x3_first_wgrad_bn(void* stream, int in_dtype, const void* images, const void* y, const void* g,
+                                          const float* scale, const float* shift, const float* mean,
+                                          const float* invstd, const float* c1, const float* c2, float* part,
+                                          float* dw, int G, int B, int IH, int IW, int OH, int OW, int pad, int R,
+                                          int CW, int flip) {
+    if (!g || !scale || !shift || !mean || !invstd || !c1 || !c2) return VQA_ERR_ARG;
+    FirstArgs a{images, nullptr, static_cast<bf16*>(const_cast<void*>(y)), nullptr, part};
+    a.wscale = nullptr;
+    a.relu = 0;
+    a.flip = flip;
+    a.g = static_cast<const bf16*>(g);
+    a.bn_scale = scale; a.bn_shift = shift; a.bn_mean = mean; a.bn_invstd = invstd; a.bn_c1 = c1; a.bn_c2 = c2;
+    return first_wgrad_launch(stream, in_dtype, a, part, dw, G, B, IH, IW, OH, OW, pad, R, CW, true);
 }

@@ -7,6 +7,7 @@
 //   conv3x3_first_wgrad  dW[16][3][3][3] = sum over pixels of dy (x) image patch, persistent workgroups over tiles;
 //                        LDS patch as 3 planes of (R+2) x (CW+2) bf16, fragment elements gathered with 2-byte LDS
 //                        reads (k-major gather offsets are per-lane constants), one 16x16x32 MFMA per 32 pixels
+//   ..._first_wgrad_bn   the same from (y, g): the BatchNorm-backward apply pass of layer 1 folded into the dy staging
 // HBM-bound: bytes = |images| + |y|.
 #include "common.h"
 #include <type_traits>

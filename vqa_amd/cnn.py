@@ -218,7 +218,8 @@ def first_wgrad(images, dy, pad, out=None, mirror=False, bn=None):
     _, OH, OW, _ = dy.shape
     R, CW = pick_first_tile(OH, OW, 384)                      # (wide tiles: long runs of dy; 0.155 -> 0.139 ms)
     tiles = B * (-(-OH // R)) * (-(-OW // CW))
-    G = min(tiles, 256 * 5)
+    # persistent workgroups: what is resident per CU (84 VGPRs -> 5 waves per SIMD; the fused kernel has 112 -> 4)
+    G = min(tiles, 256 * (4 if bn is not None else 5))
     part = torch.empty(G, 16, 32, device=dy.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty(16, 3, 3, 3, device=dy.device, dtype=torch.float32)
     tag = dict(kind='first_wgrad', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,

@@ -130,10 +130,13 @@ int vqa_cast_pad(void* stream, int src_dtype, int dst_dtype, const void* src, in
 
 /* ---------------------------------------------------------------- question encoder (gru.py:48-52, :101-106) */
 
-/* nn.Embedding gather (gru.py:103), time-major: x[t*B + b][0..ldx) = emb[q[b][t]], zero padded; q is int64 [B][T]. */
-int vqa_embed_fwd(void* stream, int dtype, const long* q, const float* emb, int B, int T, int E, void* x, int ldx);
+/* nn.Embedding gather (gru.py:103), time-major: x[t*B + b][0..ldx) = emb[q[b][t]], zero padded; q is int64 [B][T],
+ * emb [V][E].  An id outside [0, V) (nn.Embedding raises on it) reads nothing: its row becomes NaN, which reaches the
+ * loss; the backward skips it. */
+int vqa_embed_fwd(void* stream, int dtype, const long* q, const float* emb, int B, int T, int E, int V, void* x,
+                  int ldx);
 /* its backward: demb[q[b][t]] += dx[t*B + b] (demb pre-zeroed). */
-int vqa_embed_bwd(void* stream, const long* q, const float* dx, int B, int T, int E, int lddx, float* demb);
+int vqa_embed_bwd(void* stream, const long* q, const float* dx, int B, int T, int E, int V, int lddx, float* demb);
 /* nn.GRU cell gates (gru.py:104): r, z, n and h' = (1-z) n + z h from the two projections gi, gh ([B][3H], biases
  * included); save = [B][4H] (r, z, n, W_hn h + b_hn) for the backward.  H % 4 == 0 (16-byte accesses). */
 int vqa_gru_gate_fwd(void* stream, int dtype, const float* gi, const float* gh, const float* hprev, int B, int H,
@@ -142,15 +145,18 @@ int vqa_gru_gate_bwd(void* stream, int dtype, const float* dh, const float* save
                      void* dgi, void* dgh, float* dhprev);
 
 /* The whole nn.GRU recurrence (gru.py:104) in ONE persistent launch: each workgroup keeps its 48 x H slice of W_hh
- * (bf16) in LDS for all T steps, gates fused in registers, one device-wide barrier per step (bounded spin; flags[1]
- * != 0 afterwards means a barrier timed out).  bf16 only, H % 256 == 0, 48*(2H+32) <= 160 KiB; otherwise returns 1 and
- * the caller uses vqa_gemm + vqa_gru_gate_fwd per step.  gi [T][B][3H] f32, h_f / h_t [T+1][B][H] (slot 0 = zeros),
- * save [T][B][4H], flags = 2 unsigned of scratch. */
+ * (bf16) in LDS for all T steps, gates fused in registers, one device-wide barrier per step.  The grid is sized to be
+ * co-resident (occupancy query x CUs; max_wg > 0 caps it lower so the recurrence holds fewer CUs beside other work).
+ * The barrier spins are bounded: on expiry flags[1] is set and h_T (forward) / the gate gradients (backward) are
+ * written as NaN - a timeout is visible in the loss, never a silently wrong number.  bf16 only, H % 256 == 0,
+ * 48*(2H+32) <= 160 KiB; otherwise returns 1 and the caller uses vqa_gemm + vqa_gru_gate_fwd per step.
+ * gi [T][B][3H] f32, h_f / h_t [T+1][B][H] (slot 0 = zeros), save [T][B][4H], flags = 2 unsigned of scratch. */
 int vqa_gru_fwd_persistent(void* stream, const float* gi, const void* w, int ldw, const float* b_hh, float* h_f,
-                           void* h_t, float* save, int B, int T, int H, unsigned* flags);
+                           void* h_t, float* save, int B, int T, int H, unsigned* flags, int max_wg);
 /* BPTT of the same recurrence in one launch: wt = W_hh^T bf16 [H][ldw]; outputs dgi, dgh bf16 [T][B][3H]. */
 int vqa_gru_bwd_persistent(void* stream, const void* wt, int ldw, const float* h_f, const float* save,
-                           const float* dh_last, void* dgi, void* dgh, int B, int T, int H, unsigned* flags);
+                           const float* dh_last, void* dgi, void* dgh, int B, int T, int H, unsigned* flags,
+                           int max_wg);
 
 /* ---------------------------------------------------------------- attention / fusion head (vqa_model.py:83-103) */
 
@@ -174,7 +180,8 @@ int vqa_mask_mul(void* stream, int dtype, const float* x, const float* mask, lon
 /* nn.BCEWithLogitsLoss(reduction='sum') (vqa_model.py:215) and its gradient sigmoid(x) - t in one pass. */
 int vqa_bce_sum(void* stream, const float* logits, const float* target, int B, int C, int ldx, float* dlogits,
                 double* part, float* loss);
-/* vqa_model.py:127-130 without the per-sample host loop: acc[0] = sum_b target[b][argmax_c logits[b][c]]. */
+/* vqa_model.py:127-130 without the per-sample host loop: acc[0] = sum_b target[b][argmax_c logits[b][c]]; the arg-max
+ * is torch.argmax's (first maximum, NaN largest), always a valid index.  rows: B floats of scratch. */
 int vqa_soft_accuracy_sum(void* stream, const float* logits, const float* target, int B, int C, int ldx, float* rows,
                           float* acc);
 

@@ -149,8 +149,10 @@ def gru_forward(sd, q, inter=None):
     return h
 
 
-def head_forward(sd, v, q, inter=None):
-    """reference vqa_model.py:83-103 with dropout p=0 / eval (identity).  v [B,k,D], q [B,H] -> logits [B,C]."""
+def head_forward(sd, v, q, inter=None, masks=None):
+    """reference vqa_model.py:83-103.  v [B,k,D], q [B,H] -> logits [B,C].
+    masks = (noise1, noise2): the two nn.Dropout noise tensors [B,H] (keep / (1-p), vqa_model.py:55) multiplied in at
+    :101 and :103; None = dropout p=0 / eval (identity)."""
     W = {n: weight_norm_w(sd[f'{n}.weight_g'], sd[f'{n}.weight_v']) for n in HEAD_LAYERS}
     B, k, _ = v.shape
     concat = torch.cat((v, q[:, None, :].expand(B, k, q.shape[1])), dim=2)
@@ -160,20 +162,25 @@ def head_forward(sd, v, q, inter=None):
     vhat = torch.sum(p * v, dim=1)
     fv = torch.relu(vhat @ W['linear_inside_relu_image'].t() + sd['linear_inside_relu_image.bias'])
     fq = torch.relu(q @ W['linear_inside_relu_question'].t() + sd['linear_inside_relu_question.bias'])
-    m = torch.relu((fv * fq) @ W['linear_inside_relu_last'].t() + sd['linear_inside_relu_last.bias'])
+    had = fv * fq
+    if masks is not None and masks[0] is not None:
+        had = had * masks[0]
+    m = torch.relu(had @ W['linear_inside_relu_last'].t() + sd['linear_inside_relu_last.bias'])
+    if masks is not None and masks[1] is not None:
+        m = m * masks[1]
     if inter is not None:
         inter['att_p'] = p[:, :, 0]
     return m @ W['fc'].t()
 
 
-def forward(sd, images, questions, padding=2, pooling='max', training=True, new_stats=None, inter=None):
+def forward(sd, images, questions, padding=2, pooling='max', training=True, new_stats=None, inter=None, masks=None):
     """reference vqa_model.py:77-103."""
     dt = sd['cnn.convolutions.0.weight'].dtype      # fp32; tests may pass an fp64 copy for a truth run
     v = cnn_forward(sd, images.to(dt), padding, pooling, training, new_stats, inter)
     q = gru_forward(sd, questions, inter)
     if inter is not None:
         inter['cnn_out'], inter['gru_out'] = v, q
-    return head_forward(sd, v, q, inter)
+    return head_forward(sd, v, q, inter, masks)
 
 
 def bce_sum(logits, target):
@@ -193,11 +200,16 @@ def is_param(name):
                 or name.endswith('num_batches_tracked'))
 
 
-def train_step_grads(sd, images, questions, target, padding=2, pooling='max'):
+def dropout_noise(keep, p):
+    """nn.Dropout's noise tensor from a boolean keep-mask: keep / (1 - p)   (reference vqa_model.py:55)."""
+    return keep.to(torch.float32).div_(1.0 - p)
+
+
+def train_step_grads(sd, images, questions, target, padding=2, pooling='max', masks=None):
     """One fwd+bwd (reference vqa_model.py:254-256).  Returns (loss, logits, grads, new_running_stats)."""
     p = {k: (v.detach().clone().requires_grad_(True) if is_param(k) else v) for k, v in sd.items()}
     new_stats = {}
-    logits = forward(p, images, questions, padding, pooling, True, new_stats)
+    logits = forward(p, images, questions, padding, pooling, True, new_stats, None, masks)
     loss = bce_sum(logits, target)
     names = [k for k in p if is_param(k)]
     gs = torch.autograd.grad(loss, [p[k] for k in names])

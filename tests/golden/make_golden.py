@@ -1,6 +1,6 @@
 """Generate golden vectors by importing the reference's own modules (this container only).
 
-Run:  python tests/golden/make_golden.py     (needs /root/reference; writes tests/golden/*.npz)
+Run:  python tests/golden/make_golden.py [case ...]     (needs /root/reference; writes tests/golden/*.npz)
 
 The reference's cnn.py imports unmodified.  gru.py / vqa_model.py / dataset.py import `torchtext` and
 `torchvision`, which are not installed here; two tiny in-memory modules are registered in sys.modules before
@@ -34,7 +34,15 @@ CONFIGS = [
     ('h512_p0_avg', 512, 3129, 0, 'avg', 2, 224, 14),
     ('h64_p5_max', 64, 50, 5, 'max', 3, 224, 9),
     ('h128_p2_max_448', 128, 50, 2, 'max', 2, 448, 30),
+    # round 2: the benchmark's model at a batch where ReLU / arg-max flips average out (tight gradient bounds, bf16
+    # training parity) + parameters after THREE clip + Adamax steps (bias correction, running max u)
+    ('h1024_p2_max_b32', 1024, 3129, 2, 'max', 32, 224, 14),
+    # the authors' final dropout (vqa_model.py:407-416): the two nn.Dropout keep-masks of the step are captured by a
+    # forward hook on the reference's own module and stored, so the HIP path can replay them
+    ('h1024_p2_max_b32_drop', 1024, 3129, 2, 'max', 32, 224, 14),
 ]
+DROPOUT = {'h1024_p2_max_b32_drop': 0.0381}
+MULTI_STEP = {'h1024_p2_max_b32': 3}
 SEED_W, SEED_X = 42, 1234
 SAMPLE = 2048
 
@@ -95,7 +103,7 @@ def run_config(vqa_model, name, hidden, classes, padding, pooling, batch, size, 
     lpath = os.path.join(tmp, f'label2ans_{classes}.pkl')
     pickle.dump([f'ans{i}' for i in range(classes)], open(lpath, 'wb'))
     model = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': hidden, 'n_layers': 1,
-                           'train_question_path': qpath}, lpath, 256, padding, 0.0, pooling, 'relu')
+                           'train_question_path': qpath}, lpath, 256, padding, DROPOUT.get(name, 0.0), pooling, 'relu')
     vocab = len(model.gru.word_idx_mappings)
     sd = synth.state_dict(SEED_W, hidden, classes, vocab)
     model.load_state_dict(sd, strict=True)
@@ -134,9 +142,24 @@ def run_config(vqa_model, name, hidden, classes, padding, pooling, batch, size, 
             m.running_mean.copy_(sd_lookup(sd, model, m, 'running_mean'))
             m.running_var.copy_(sd_lookup(sd, model, m, 'running_var'))
             m.num_batches_tracked.zero_()
+    keeps = []
+    if name in DROPOUT:
+        # nn.Dropout computes input * noise with noise = bernoulli(1-p) / (1-p) (vqa_model.py:55, :101, :103).  Where
+        # the input is exactly 0 (inactive ReLU units) the draw is unobservable and irrelevant: the forward value and
+        # every gradient through that element are 0 whatever the mask says; it is stored as "kept".
+        def hook(_m, inp, outp):
+            keeps.append(((outp != 0) | (inp[0] == 0)).numpy())
+        handle = model.dropout.register_forward_hook(hook)
+        torch.manual_seed(777)
     logits = model(img.float(), q)
     loss = crit(logits, tgt)
     loss.backward()
+    if name in DROPOUT:
+        handle.remove()
+        assert len(keeps) == 2
+        out['dropout_p'] = np.float64(DROPOUT[name])
+        out['keep1'], out['keep2'] = np.packbits(keeps[0]), np.packbits(keeps[1])
+        print('  dropout: dropped', int((~keeps[0]).sum()), int((~keeps[1]).sum()), 'of', keeps[0].size)
     out['logits'], out['loss'] = logits.detach().numpy(), np.float64(loss)
     for n, p in model.named_parameters():
         g = p.grad.detach().reshape(-1)
@@ -154,6 +177,22 @@ def run_config(vqa_model, name, hidden, classes, padding, pooling, batch, size, 
         f = p.detach().reshape(-1)
         out[f'pnorm/{n}'] = np.float64(f.double().norm())
         out[f'psamp/{n}'] = f.numpy()[sample_idx(f.numel())]
+    # ---- further steps on the same batch (vqa_model.py:247-266 per iteration, no flip)
+    for s in range(2, MULTI_STEP.get(name, 1) + 1):
+        opt.zero_grad()
+        loss_s = crit(model(img.float(), q), tgt)
+        loss_s.backward()
+        out[f'loss{s}'] = np.float64(loss_s)
+        out[f'total_norm{s}'] = np.float64(torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=0.25,
+                                                                          norm_type=2))
+        opt.step()
+        if s == MULTI_STEP[name]:
+            for n, p in model.named_parameters():
+                out[f'p{s}samp/{n}'] = p.detach().reshape(-1).numpy()[sample_idx(p.numel())]
+            for n, b in model.named_buffers():
+                if 'running' in n:
+                    out[f'stat{s}/{n}'] = b.detach().numpy().copy()
+        print(f'  step {s}: loss={float(loss_s):.6f} total_norm={float(out[f"total_norm{s}"]):.6f}')
     np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
     print(f'{name}: loss={float(loss):.6f} total_norm={float(total):.6f} vocab={vocab} '
           f'eval_acc_sum={out["eval_acc_sum"]}')
@@ -172,8 +211,10 @@ def main():
     import vqa_model  # the reference's module
     torch.manual_seed(0)
     with tempfile.TemporaryDirectory() as tmp:
+        only = sys.argv[1:]                                   # optional: names of the cases to (re)generate
         for cfg in CONFIGS:
-            run_config(vqa_model, *cfg, tmp)
+            if not only or cfg[0] in only:
+                run_config(vqa_model, *cfg, tmp)
 
 
 if __name__ == '__main__':

@@ -15,6 +15,11 @@ CONFIGS = {
     'h512_p0_avg': (512, 3129, 0, 'avg', 2, 224, 14),
     'h64_p5_max': (64, 50, 5, 'max', 3, 224, 9),
     'h128_p2_max_448': (128, 50, 2, 'max', 2, 448, 30),
+    'h1024_p2_max_b32': (1024, 3129, 2, 'max', 32, 224, 14),      # + parameters after 3 clip + Adamax steps
+}
+# cases with the reference's dropout > 0: the two keep-masks of the recorded step are part of the golden file
+DROPOUT_CONFIGS = {
+    'h1024_p2_max_b32_drop': (1024, 3129, 2, 'max', 32, 224, 14),
 }
 
 
@@ -25,7 +30,7 @@ def sample_idx(n):
 
 
 def load_case(name):
-    hidden, classes, padding, pooling, batch, size, tokens = CONFIGS[name]
+    hidden, classes, padding, pooling, batch, size, tokens = (CONFIGS.get(name) or DROPOUT_CONFIGS[name])
     g = np.load(os.path.join(GOLDEN_DIR, f'{name}.npz'))
     vocab = int(g['vocab'])
     case = dict(hidden=hidden, classes=classes, padding=padding, pooling=pooling, batch=batch, size=size,
@@ -34,6 +39,11 @@ def load_case(name):
                 images=synth.images(SEED_X, batch, size),
                 questions=synth.questions(SEED_X, batch, tokens, vocab),
                 targets=synth.targets(SEED_X, batch, classes))
+    if 'dropout_p' in g.files:
+        p = float(g['dropout_p'])
+        keep = [torch.from_numpy(np.unpackbits(g[k])[:batch * hidden].reshape(batch, hidden).astype(bool))
+                for k in ('keep1', 'keep2')]
+        case.update(dropout=p, keep=keep, noise=[k.to(torch.float32).div_(1.0 - p) for k in keep])
     return case
 
 
@@ -65,8 +75,8 @@ def build_model(case, tmp, precision):
     import vqa_model
     qpath, lpath = fixture_files(tmp, case['classes'])
     m = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': case['hidden'], 'n_layers': 1,
-                       'train_question_path': qpath}, lpath, 256, case['padding'], 0.0, case['pooling'], 'relu',
-                      precision=precision)
+                       'train_question_path': qpath}, lpath, 256, case['padding'], case.get('dropout', 0.0),
+                      case['pooling'], 'relu', precision=precision)
     assert len(m.gru.word_idx_mappings) == case['vocab']
     m.load_state_dict(case['sd'], strict=True)
     return m

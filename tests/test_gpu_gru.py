@@ -19,7 +19,11 @@ def _mk(H, V, tmp_path, prec):
 @pytest.mark.parametrize('prec,H,B,T,tol,persistent',
                          [('fp32', 64, 5, 7, 2e-5, False), ('fp32', 256, 3, 14, 2e-5, False),
                           ('bf16', 256, 70, 14, 3e-2, False), ('bf16', 512, 130, 9, 3e-2, False),
-                          ('bf16', 256, 70, 14, 3e-2, True), ('bf16', 512, 130, 9, 3e-2, True)])
+                          ('bf16', 256, 70, 14, 3e-2, True), ('bf16', 512, 130, 9, 3e-2, True),
+                          # the benchmark's shape (configs[1]) on both launch structures, and configs[4]'s large hidden
+                          # size (the persistent kernel's W_hh slice no longer fits LDS there: it must fall back)
+                          ('bf16', 1024, 256, 14, 3e-2, False), ('bf16', 1024, 256, 14, 3e-2, True),
+                          ('bf16', 2048, 64, 30, 3e-2, True)])
 def test_gru_vs_oracle(prec, H, B, T, tol, persistent, tmp_path, monkeypatch):
     from oracle import vqa_oracle as O
     from vqa_amd import synth

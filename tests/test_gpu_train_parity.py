@@ -1,0 +1,256 @@
+"""GPU: parity of the TRAINING path at the benchmark's precision and model size.
+
+* the fusion head in bf16 (attn_bwd / hadamard_bwd / relu_bwd / group_sum / the TN GEMMs in their bf16 instantiations)
+  against the oracle's autograd on given encoder outputs;
+* the whole model, fp32 and bf16, against the B=32 golden captured from the imported reference (H=1024, padding 2,
+  224x224): at this batch the ReLU / arg-max flips of the tiny-batch goldens average out and the bounds tighten;
+* dropout p = 0.0381 (the authors' final config) with the reference's recorded keep-masks replayed;
+* three clip + Adamax steps against the reference's parameters, and the fused optimizer element-wise against
+  torch.optim.Adamax + clip_grad_norm_ (the calls at vqa_model.py:259, :218, :266)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_model, load_case, rel_err, sample_idx
+
+pytestmark = pytest.mark.gpu
+
+
+def _is_conv_bias(k):
+    from oracle import vqa_oracle as O
+    return k.startswith('cnn.convolutions') and k.endswith('.bias') and int(k.split('.')[2]) in O.CONV_IDX
+
+
+# bf16 bounds per head tensor (measured in brackets): activations / weights are rounded to 8 mantissa bits at every
+# GEMM input, accumulation is fp32
+HEAD_BF16 = dict(logits=1.5e-2, dv=2.5e-2, dq=2.5e-2, grad=2.5e-2, weight_g=4e-2)
+
+
+@pytest.mark.parametrize('K,H,B', [(25, 1024, 32), (144, 512, 24), (25, 512, 40), (144, 1024, 16)])
+@pytest.mark.parametrize('prec', ['bf16', 'fp32'])
+def test_head_fwd_bwd_vs_oracle(prec, K, H, B, tmp_path):
+    """_HeadFunction on GIVEN fp32 v [B,k,256], q [B,H]: logits, dv, dq and all 16 head parameter gradients against
+    oracle.head_forward autograd (vqa_model.py:83-103) with the sum-BCE loss on top (:215)."""
+    import vqa_model
+    from oracle import vqa_oracle as O
+    from vqa_amd import synth
+    C = 3129
+    case = dict(hidden=H, classes=C, padding=2, pooling='max', vocab=82, sd=synth.state_dict(42, H, C, 82))
+    m = build_model(case, tmp_path, prec).cuda().train()
+    v = torch.relu(synth.uniform(5, 'head.v', (B, K, 256), -0.6, 1.4))      # pooled post-ReLU features, some zeros
+    q = synth.uniform(5, 'head.q', (B, H), -1.0, 1.0)                       # GRU hidden state range
+    t = synth.targets(5, B, C)
+    p = {k: (x.clone().requires_grad_(True) if O.is_param(k) else x) for k, x in case['sd'].items()
+         if not k.startswith(('cnn.', 'gru.'))}
+    vr, qr = v.clone().requires_grad_(True), q.clone().requires_grad_(True)
+    lo_ref = O.head_forward(p, vr, qr)
+    O.bce_sum(lo_ref, t).backward()
+    vd, qd = v.cuda().requires_grad_(True), q.cuda().requires_grad_(True)
+    lo = m.head(vd, qd)
+    vqa_model.SoftScoreBCELoss()(lo, t.cuda()).backward()
+    tol = HEAD_BF16 if prec == 'bf16' else dict(logits=2e-5, dv=2e-4, dq=2e-4, grad=5e-4, weight_g=2e-3)
+    errs = dict(logits=rel_err(lo.detach().cpu(), lo_ref.detach()), dv=rel_err(vd.grad.cpu(), vr.grad),
+                dq=rel_err(qd.grad.cpu(), qr.grad))
+    for k, e in errs.items():
+        assert e < tol[k], (k, e)
+    worst = {}
+    for k, prm in m.named_parameters():
+        if k.startswith(('cnn.', 'gru.')):
+            continue
+        e = rel_err(prm.grad.cpu(), p[k].grad)
+        grp = 'weight_g' if k.endswith('weight_g') else 'grad'
+        worst[grp] = max(worst.get(grp, 0.0), e)
+        assert e < tol[grp], (k, e)
+    print(f'\n[head {prec} K={K} H={H} B={B}] ' + ' '.join(f'{k} {e:.2e}' for k, e in {**errs, **worst}.items()))
+
+
+# whole model against the B=32 golden: bound per parameter group (measured in brackets; fp32 / bf16)
+B32_TOL = {
+    'fp32': dict(logits=1e-4, loss=3e-4, cnn=1e-2, weight_g=2e-3, rest=5e-4, stats=1e-4),
+    'bf16': dict(logits=3e-2, loss=5e-3, cnn=2.5e-1, weight_g=1e-1, rest=5e-2, stats=5e-3),
+}
+
+
+def _check_train_step(m, c, prec, noise=None):
+    import vqa_model
+    g = c['golden']
+    tol = B32_TOL[prec]
+    img, q, t = c['images'].cuda(), c['questions'].cuda(), c['targets'].cuda()
+    logits = m(img, q, dropout_noise=noise)
+    loss = vqa_model.SoftScoreBCELoss()(logits, t)
+    loss.backward()
+    e_logits = rel_err(logits.detach().cpu(), g['logits'])
+    e_loss = abs(float(loss.detach()) - float(g['loss'])) / abs(float(g['loss']))
+    assert e_logits < tol['logits'] and e_loss < tol['loss'], (e_logits, e_loss)
+    for k, b in m.named_buffers():
+        if 'running' in k:
+            assert rel_err(b.cpu(), g[f'stat/{k}']) < tol['stats'], k
+    worst = {}
+    for k, p in m.named_parameters():
+        flat = p.grad.detach().reshape(-1).cpu()
+        if _is_conv_bias(k):
+            assert float(flat.abs().max()) == 0.0
+            continue
+        grp = 'cnn' if k.startswith('cnn.') else ('weight_g' if k.endswith('weight_g') else 'rest')
+        e = rel_err(flat.numpy()[sample_idx(flat.numel())], g[f'gsamp/{k}'])
+        en = abs(float(flat.double().norm()) - float(g[f'gnorm/{k}'])) / float(g[f'gnorm/{k}'])
+        worst[grp] = max(worst.get(grp, 0.0), e)
+        worst[grp + '_norm'] = max(worst.get(grp + '_norm', 0.0), en)
+        assert e < tol[grp] and en < tol[grp], (k, e, en)
+    return e_logits, e_loss, worst
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_b32_train_step_vs_golden(prec, tmp_path):
+    """Full training forward + backward at H=1024, padding 2, 224x224, B=32 against the imported reference."""
+    c = load_case('h1024_p2_max_b32')
+    m = build_model(c, tmp_path, prec).cuda().train()
+    e_logits, e_loss, worst = _check_train_step(m, c, prec)
+    print(f'\n[b32 {prec}] logits {e_logits:.2e} loss {e_loss:.2e} ' + ' '.join(f'{k} {e:.2e}' for k, e in worst.items()))
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_dropout_replayed_vs_golden(prec, tmp_path):
+    """Dropout p = 0.0381 (vqa_model.py:55, :101, :103, :407-416): with the reference's two recorded keep-masks the HIP
+    path reproduces its logits, loss and gradients; without them (its own draws) it does not - the masks are live."""
+    c = load_case('h1024_p2_max_b32_drop')
+    m = build_model(c, tmp_path, prec).cuda().train()
+    assert m.dropout_p == pytest.approx(0.0381)
+    e_logits, e_loss, worst = _check_train_step(m, c, prec, noise=[n.cuda() for n in c['noise']])
+    print(f'\n[drop {prec}] logits {e_logits:.2e} loss {e_loss:.2e} ' + ' '.join(f'{k} {e:.2e}' for k, e in worst.items()))
+    m.zero_grad(set_to_none=True)
+    torch.manual_seed(1)
+    own = m(c['images'].cuda(), c['questions'].cuda())                        # its own Bernoulli draws
+    assert rel_err(own.detach().cpu(), c['golden']['logits']) > 10 * B32_TOL['fp32']['logits']
+    # the module's own draws are inverted dropout: kept fraction ~ 1 - p, kept values scaled by 1 / (1 - p)
+    mask = m._dropout_mask(4096, torch.device('cuda'))
+    assert abs(float((mask > 0).float().mean()) - (1 - 0.0381)) < 5e-3
+    assert float(mask.max()) == pytest.approx(1 / (1 - 0.0381), rel=1e-6)
+    m.eval()
+    assert m._dropout_mask(4, torch.device('cuda')) is None
+
+
+@pytest.mark.parametrize('prec,tol_scalar,tol_update', [('fp32', 5e-3, 1e-2), ('bf16', 5e-2, 8e-2)])
+def test_three_steps_vs_golden(prec, tol_scalar, tol_update, tmp_path):
+    """Three whole training steps (Trainer: zero_grad -> fwd -> loss -> bwd -> clip 0.25 -> Adamax) on the B=32 case
+    against the reference's state after its third step: losses and clip norms of steps 2 and 3, running statistics,
+    and the accumulated updates of the smoothly-behaving parameters (tests/test_oracle_golden.py::SMOOTH)."""
+    from tests.test_oracle_golden import check_three_steps
+    from vqa_amd.optim import Trainer
+    c = load_case('h1024_p2_max_b32')
+    m = build_model(c, tmp_path, prec).cuda().train()
+    tr = Trainer(m, lr=2e-3, max_norm=0.25)
+    img, q, t = c['images'].cuda(), c['questions'].cuda(), c['targets'].cuda()
+    losses, norms = [], []
+    for _ in range(3):
+        losses.append(float(tr.step(img, q, t, flip=False)))
+        norms.append(float(tr.opt.total_norm))
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    worst = check_three_steps(c, sd, losses, norms, tol_scalar=tol_scalar, tol_update=tol_update)
+    for k in range(10):
+        assert int(m.cnn.convolutions[[1, 4, 8, 11, 15, 18, 22, 25, 29, 32][k]].num_batches_tracked) == 3
+    print(f'\n[3 steps {prec}] losses {losses} norms {norms} worst mean |update diff| / lr {worst:.2e}')
+
+
+def test_clip_adamax_vs_torch_optim():
+    """vqa_clip_adamax element-wise against nn.utils.clip_grad_norm_(0.25) + torch.optim.Adamax(lr=2e-3) (the calls
+    at vqa_model.py:259, :218, :266) over six steps of synthetic gradients whose scale shrinks and grows - so the
+    running max u alternates between its decayed value and |g| + eps, the bias correction runs past step 1, and the
+    norm falls on both sides of the clip threshold."""
+    from vqa_amd import synth
+    from vqa_amd.optim import FlatAdamax, FlatParams
+    mod = torch.nn.ParameterDict({'a': torch.nn.Parameter(synth.uniform(1, 'p.a', (257, 33), -1, 1)),
+                                  'b': torch.nn.Parameter(synth.uniform(1, 'p.b', (1000,), -1, 1))}).cuda()
+    ref = {k: torch.nn.Parameter(v.detach().cpu().clone()) for k, v in mod.items()}
+    opt_ref = torch.optim.Adamax(ref.values(), lr=2e-3)
+    flat = FlatParams(mod)
+    opt = FlatAdamax(flat, lr=2e-3, max_norm=0.25)
+    for step, scale in enumerate([1.0, 1e-3, 5e-6, 3.0, 1e-4, 0.5]):
+        for k in ref:
+            g = synth.uniform(2 + step, 'g.' + k, tuple(ref[k].shape), -1, 1) * scale
+            ref[k].grad = g.clone()
+            mod[k].grad = None
+            mod[k]._vqa_grad_dst.copy_(g.reshape(-1))
+            mod[k].grad = mod[k]._vqa_grad_dst.view(mod[k].shape)
+        total_ref = torch.nn.utils.clip_grad_norm_(ref.values(), max_norm=0.25, norm_type=2)
+        opt_ref.step()
+        opt.step()
+        assert float(opt.total_norm) == pytest.approx(float(total_ref), rel=1e-6)
+        for k in ref:
+            assert torch.allclose(mod[k].detach().cpu(), ref[k].detach(), rtol=0, atol=3e-7), (k, step)
+
+
+@pytest.mark.parametrize('prec', ['bf16', 'fp32'])
+def test_gradient_accumulation_with_side_streams(prec, tmp_path, monkeypatch):
+    """with an existing p.grad (two backward calls without zero_grad, or zero_grad(set_to_none=False))
+    autograd runs `p.grad += g` on the calling stream right after the head's backward returns - the head's parameter
+    gradients, computed on the weight-gradient stream, must be finished by then.  Streams on vs off, bit for bit."""
+    import vqa_model
+    from vqa_amd import cnn as CN, vqa_model as VM
+    c = load_case('h64_p5_max')
+    img, q, t = c['images'].cuda(), c['questions'].cuda(), c['targets'].cuda()
+    crit = vqa_model.SoftScoreBCELoss()
+    out = []
+    for streams in (True, False):
+        monkeypatch.setattr(VM, 'SIDE_STREAM', streams)
+        monkeypatch.setattr(VM, 'HEAD_WGRAD_STREAM', streams)
+        monkeypatch.setattr(CN, 'WGRAD_STREAM', streams)
+        m = build_model(c, tmp_path, prec).cuda().train()
+        m.zero_grad(set_to_none=True)
+        crit(m(img, q), t).backward()
+        crit(m(img.flip(0), q.flip(0)), t.flip(0)).backward()              # accumulates into the existing grads
+        twice = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        m.zero_grad(set_to_none=False)                                     # grads stay allocated, zeroed
+        crit(m(img, q), t).backward()
+        seen = []
+        h = m.fc.weight_v.register_hook(lambda g: seen.append(g.clone()))  # a tensor hook reads the gradient at once
+        m.zero_grad(set_to_none=True)
+        crit(m(img, q), t).backward()
+        h.remove()
+        out.append((twice, {k: p.grad.detach().clone() for k, p in m.named_parameters()}, seen[0]))
+    for a, b in zip(out[0][:2], out[1][:2]):
+        for k in a:
+            if k == 'gru.word_embedding.weight' and not torch.equal(a[k], b[k]):
+                assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7)      # (float atomics, if still in use)
+            else:
+                assert torch.equal(a[k], b[k]), k
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][2], out[0][1]['fc.weight_v'])
+
+
+def test_soft_accuracy_on_nan_and_inf_rows():
+    """A diverged model reaching evaluate(): rows of NaN / -inf logits.  torch.argmax returns a valid index (the first
+    NaN, else the first maximum) and the reference's loop carries on (vqa_model.py:127-130); so must the kernels -
+    and never gather out of range."""
+    from vqa_amd import ops, synth
+    B, C, L = 9, 3129, 10
+    torch.manual_seed(0)
+    x = torch.randn(B, C)
+    x[1] = float('nan')
+    x[2] = float('-inf')
+    x[3, 100:] = float('nan')                       # first NaN at 100
+    x[4, 7] = float('inf')
+    x[5] = 0.25                                     # all equal: first index
+    x[6, 2000] = float('nan'); x[6, 5] = float('inf')
+    t = synth.targets(3, B, C)
+    t[1, 0] = 0.9; t[2, 0] = 0.6; t[3, 100] = 1.0; t[4, 7] = 0.3; t[5, 0] = 0.3; t[6, 2000] = 0.6
+    want = float(t[torch.arange(B), torch.argmax(x, dim=1)].sum())
+    assert float(ops.soft_accuracy_sum(x.cuda(), t.cuda())) == pytest.approx(want, abs=1e-6)
+    labels = torch.full((B, L), -1, dtype=torch.int64)
+    scores = torch.zeros(B, L)
+    for b in range(B):
+        nz = t[b].nonzero().flatten()
+        labels[b, :len(nz)] = nz
+        scores[b, :len(nz)] = t[b, nz]
+    assert float(ops.soft_accuracy_sum(x.cuda(), (labels.cuda(), scores.cuda()))) == pytest.approx(want, abs=1e-6)
+
+
+def test_out_of_vocabulary_token_poisons_instead_of_faulting(tmp_path):
+    """A token id outside the embedding table (nn.Embedding raises IndexError): the gather reads nothing, the row
+    becomes NaN and reaches the output; the backward leaves the table's gradient untouched by it."""
+    from tests.test_gpu_gru import _mk
+    g, _ = _mk(64, 82, tmp_path, 'fp32')
+    q = torch.randint(2, 82, (4, 6))
+    q[2, 3] = 82
+    q[3, 0] = -5
+    h = g(q.cuda())
+    assert torch.isfinite(h[:2]).all() and torch.isnan(h[2]).all() and torch.isnan(h[3]).all()

@@ -68,7 +68,19 @@ def call(name, *args):
         _FN[name] = fn
     status = fn(_raw_stream(), *[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args])
     if status != 0:
-        raise VqaHipError(f'{name} failed with status {status}')
+        raise VqaHipError(f'{name} failed with status {status}', status)
+
+
+def fits(name, *args):
+    """call() for the entry points that document status 1 as "this shape is not mine, use the general path" (the
+    persistent recurrence): False on status 1 (nothing was launched), True on success, raises on anything else."""
+    try:
+        call(name, *args)
+    except VqaHipError as e:
+        if len(e.args) > 1 and e.args[1] == 1:
+            return False
+        raise
+    return True
 
 
 def declared_symbols():

@@ -7,8 +7,10 @@
 // separated by one device-wide barrier (monotonic counter, agent-scope release / acquire, bounded spin).
 // The backward kernel mirrors it: W_hh^T slice resident in LDS, gate derivatives in registers, one barrier per step.
 //
-// All workgroups must be co-resident: grid = (H/16) * NB <= 256 with one workgroup per CU (LDS-bound), checked on the
-// host.  Every spin is bounded: on expiry the kernel sets flags[1] and runs on (wrong numbers, never a hang).
+// All workgroups must be co-resident: grid = (H/16) * NB <= resident workgroups per CU (occupancy query) x CUs, checked
+// on the host.  Every spin is bounded: on expiry the kernel sets flags[1] and runs on, and every workgroup that sees
+// the marker in its last step writes NaN instead of its results - a timed-out barrier poisons h_T / the gate
+// gradients, reaches the loss and the gradient norm, and is never a silently wrong number (nor a hang).
 #include "common.h"
 
 namespace {
@@ -83,6 +85,9 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent(GruArgs a) {
 
     const int row_base = bt * a.rows_per_wg;
     for (int t = 0; t < a.T; ++t) {
+        // last step: a barrier that timed out anywhere (flags[1]) turns this workgroup's h_T into NaN
+        const float poison = (t + 1 == a.T && __hip_atomic_load(a.flags + 1, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT) != 0u) ? NAN : 0.f;
         const bf16* hp_t = a.h_t + (long)t * B * H;
         const float* hp_f = a.h_f + (long)t * B * H;
         float* hn_f = a.h_f + (long)(t + 1) * B * H;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent(GruArgs a) {
                     zz[e] = sigm(giz[e] + acc[1][e] + bh[1][e]);
                     hn[e] = acc[2][e] + bh[2][e];
                     nn[e] = tanhf(gin[e] + rr[e] * hn[e]);
-                    hh[e] = (1.f - zz[e]) * nn[e] + zz[e] * hpv[e];
+                    hh[e] = (1.f - zz[e]) * nn[e] + zz[e] * hpv[e] + poison;
                 }
                 store_vec4<float>(hn_f + (long)b * H + j, hh);
                 store_vec4<bf16>(hn_t + (long)b * H + j, hh);
@@ -191,6 +196,8 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent(GruArgs a) {
     unsigned epoch = 0;
     for (int t = a.T - 1; t >= 0; --t) {
         float part[MAXC][4];
+        const float poison = (t == 0 && __hip_atomic_load(a.flags + 1, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT) != 0u) ? NAN : 0.f;
         // ---- phase A: gate derivatives of step t for the owned (rows, units)
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent(GruArgs a) {
                 float dr[4], dz[4], dn[4], dnr[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float g = dh[c][e];
+                    const float g = dh[c][e] + poison;
                     dn[e] = g * (1.f - zz[e]) * (1.f - nn[e] * nn[e]);
                     dz[e] = g * (hp[e] - nn[e]) * zz[e] * (1.f - zz[e]);
                     dr[e] = dn[e] * hn[e] * rr[e] * (1.f - rr[e]);
@@ -254,23 +261,44 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent(GruArgs a) {
 
 }  // namespace
 
+// Largest co-resident grid of a persistent kernel with `lds` bytes of dynamic LDS: occupancy x CUs of the current
+// device (queried per call: two cheap runtime calls; no state is cached, the library stays re-entrant).
+template <typename K>
+static int resident_workgroups(K kernel, size_t lds) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess) return 0;
+    return cus * per_cu;
+}
+
+// batch slabs: as many as fill the resident grid (or max_wg, if the caller wants the recurrence to hold fewer CUs)
+static int gru_slabs(int B, int nj, int resident, int max_wg) {
+    int cap = resident;
+    if (max_wg > 0 && max_wg < cap) cap = max_wg;
+    if (nj > cap) return 0;
+    int nb = (B + 63) / 64;
+    if (nb > cap / nj) nb = cap / nj;
+    return nb;
+}
+
 // gru persistent forward.  w = W_hh bf16 [3H][ldw].  flags: 2 unsigned (zeroed here).  Returns 1 if the shape does not
 // fit the resident-weight scheme (caller falls back to per-step launches).
 extern "C" int vqa_gru_fwd_persistent(void* stream, const float* gi, const void* w, int ldw, const float* b_hh,
-                                      float* h_f, void* h_t, float* save, int B, int T, int H, unsigned* flags) {
+                                      float* h_f, void* h_t, float* save, int B, int T, int H, unsigned* flags,
+                                      int max_wg) {
     if (H % 256 || B < 1 || T < 1) return VQA_ERR_ARG;
     const size_t lds = (size_t)48 * (H * 2 + 32);
     if (lds > 160 * 1024) return VQA_ERR_ARG;
     const int nj = H / 16;
-    if (nj > 256) return VQA_ERR_ARG;
-    int nb = (B + 63) / 64;
-    if (nb > 256 / nj) nb = 256 / nj;
+    (void)hipFuncSetAttribute((const void*)gru_fwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int nb = gru_slabs(B, nj, resident_workgroups(gru_fwd_persistent, lds), max_wg);
+    if (nb < 1) return VQA_ERR_ARG;
     const int rows_per_wg = ((B + nb - 1) / nb + 15) / 16 * 16;
     GruArgs a{gi, static_cast<const bf16*>(w), ldw, b_hh, h_f, static_cast<bf16*>(h_t), save, nullptr, nullptr, nullptr,
               B, T, H, rows_per_wg, flags};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), s) != hipSuccess) return VQA_ERR_LAUNCH;
-    (void)hipFuncSetAttribute((const void*)gru_fwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(gru_fwd_persistent, dim3(nj * nb), dim3(256), lds, s, a);
     CHECK_LAUNCH();
     return VQA_OK;
@@ -279,14 +307,14 @@ extern "C" int vqa_gru_fwd_persistent(void* stream, const float* gi, const void*
 // gru persistent backward.  wt = W_hh^T bf16 [H][ldw] (3H contiguous).  dgi / dgh: bf16 [T][B][3H] outputs.
 extern "C" int vqa_gru_bwd_persistent(void* stream, const void* wt, int ldw, const float* h_f, const float* save,
                                       const float* dh_last, void* dgi, void* dgh, int B, int T, int H,
-                                      unsigned* flags) {
+                                      unsigned* flags, int max_wg) {
     if (H % 256 || B < 1 || T < 1) return VQA_ERR_ARG;
     const size_t lds = (size_t)16 * (3 * H * 2 + 32);
     if (lds > 160 * 1024) return VQA_ERR_ARG;
     const int nj = H / 16;
-    if (nj > 256) return VQA_ERR_ARG;
-    int nb = (B + 63) / 64;
-    if (nb > 256 / nj) nb = 256 / nj;
+    (void)hipFuncSetAttribute((const void*)gru_bwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int nb = gru_slabs(B, nj, resident_workgroups(gru_bwd_persistent, lds), max_wg);
+    if (nb < 1) return VQA_ERR_ARG;
     const int rows_per_wg = ((B + nb - 1) / nb + 15) / 16 * 16;
     if (rows_per_wg > 256) return VQA_ERR_ARG;           // 4 row chunks per wave are kept in registers
     GruArgs a{nullptr, static_cast<const bf16*>(wt), ldw, nullptr, const_cast<float*>(h_f), nullptr,
@@ -294,7 +322,6 @@ extern "C" int vqa_gru_bwd_persistent(void* stream, const void* wt, int ldw, con
               flags};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), s) != hipSuccess) return VQA_ERR_LAUNCH;
-    (void)hipFuncSetAttribute((const void*)gru_bwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(gru_bwd_persistent, dim3(nj * nb), dim3(256), lds, s, a);
     CHECK_LAUNCH();
     return VQA_OK;

@@ -228,19 +228,23 @@ __global__ void cast_pad(const TS* __restrict__ src, int M, int N, int lds, TD* 
 
 // ---------------------------------------------------------------------------------------- embedding
 // X[t][b][0..ldx) = emb[q[b][t]][0..E), zero padded   (time-major so every GRU step reads a contiguous slab)
+// A token id outside [0, V) (nn.Embedding raises on it) reads nothing: its row is filled with NaN, which reaches the
+// loss and fails the step visibly instead of faulting the GPU; the backward skips it.
 template <typename T>
-__global__ void embed_fwd(const long* q, const float* emb, int B, int Tn, int E, T* x, int ldx) {
+__global__ void embed_fwd(const long* q, const float* emb, int B, int Tn, int E, int V, T* x, int ldx) {
     const int row = blockIdx.x;          // t*B + b
     const int t = row / B, b = row % B;
     const long id = q[(long)b * Tn + t];
+    const bool ok = id >= 0 && id < V;
     for (int e = threadIdx.x; e < ldx; e += blockDim.x)
-        x[(long)row * ldx + e] = from_f32<T>(e < E ? emb[id * E + e] : 0.f);
+        x[(long)row * ldx + e] = from_f32<T>(e < E ? (ok ? emb[id * E + e] : NAN) : 0.f);
 }
 // demb[q[b][t]][e] += dx[t*B+b][e]
-__global__ void embed_bwd(const long* q, const float* dx, int B, int Tn, int E, int lddx, float* demb) {
+__global__ void embed_bwd(const long* q, const float* dx, int B, int Tn, int E, int V, int lddx, float* demb) {
     const int row = blockIdx.x;
     const int t = row / B, b = row % B;
     const long id = q[(long)b * Tn + t];
+    if (id < 0 || id >= V) return;
     for (int e = threadIdx.x; e < E; e += blockDim.x) atomicAdd(&demb[id * E + e], dx[(long)row * lddx + e]);
 }
 
@@ -568,20 +572,30 @@ __global__ __launch_bounds__(256) void bce_partial(const float* __restrict__ x, 
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = r[0] + r[1] + r[2] + r[3];
 }
-// acc_part[b] = target[b][argmax_c logits[b][c]]  (first maximum, as torch.argmax)
-__global__ void soft_acc_rows(const float* x, const float* t, int C, int ldx, float* out) {
-    const int b = blockIdx.x, lane = threadIdx.x;   // one wave per row
+// torch.argmax over one row by one wave: the FIRST maximum, NaN counting as larger than everything (so a row of NaN
+// or of -inf - a diverged model reaching evaluate() - still yields a valid index, 0 .. C-1, as the reference's
+// torch.argmax does at vqa_model.py:127, and never an out-of-range gather).
+__device__ __forceinline__ bool arg_gt(float a, float b) { return a > b || (a != a && b == b); }
+__device__ __forceinline__ int row_argmax(const float* xr, int C, int lane) {
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int c = lane; c < C; c += 64) {
-        const float v = x[(long)b * ldx + c];
-        if (v > best) { best = v; bi = c; }
+    if (lane < C) { best = xr[lane]; bi = lane; }
+    for (int c = lane + 64; c < C; c += 64) {
+        const float v = xr[c];
+        if (arg_gt(v, best)) { best = v; bi = c; }
     }
     for (int o = 1; o < 64; o <<= 1) {
         const float ob = __shfl_xor(best, o);
         const int oi = __shfl_xor(bi, o);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        const bool same = ob == best || (ob != ob && best != best);
+        if (arg_gt(ob, best) || (same && oi < bi)) { best = ob; bi = oi; }
     }
+    return (unsigned)bi < (unsigned)C ? bi : 0;
+}
+// acc_part[b] = target[b][argmax_c logits[b][c]]
+__global__ void soft_acc_rows(const float* x, const float* t, int C, int ldx, float* out) {
+    const int b = blockIdx.x, lane = threadIdx.x;   // one wave per row
+    const int bi = row_argmax(x + (long)b * ldx, C, lane);
     if (lane == 0) out[b] = t[(long)b * C + bi];
 }
 // Sparse soft-score targets: row b has L slots (label, score), label < 0 = empty slot, labels distinct within a row -
@@ -616,17 +630,7 @@ __global__ __launch_bounds__(256) void bce_sparse_rows(const float* x, const lon
 __global__ void soft_acc_rows_sparse(const float* x, const long* labels, const float* scores, int C, int L, int ldx,
                                      float* out) {
     const int b = blockIdx.x, lane = threadIdx.x;   // one wave per row
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int c = lane; c < C; c += 64) {
-        const float v = x[(long)b * ldx + c];
-        if (v > best) { best = v; bi = c; }
-    }
-    for (int o = 1; o < 64; o <<= 1) {
-        const float ob = __shfl_xor(best, o);
-        const int oi = __shfl_xor(bi, o);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
+    const int bi = row_argmax(x + (long)b * ldx, C, lane);
     float sc = 0.f;
     for (int l = lane; l < L; l += 64)
         if (labels[(long)b * L + l] == bi) sc = scores[(long)b * L + l];
@@ -784,16 +788,19 @@ extern "C" int vqa_cast_pad(void* stream, int src_dtype, int dst_dtype, const vo
     return VQA_OK;
 }
 
-extern "C" int vqa_embed_fwd(void* stream, int dtype, const long* q, const float* emb, int B, int T, int E, void* x,
-                             int ldx) {
-    BY_T(dtype, hipLaunchKernelGGL(embed_fwd<bf16>, dim3(B * T), dim3(128), 0, ST, q, emb, B, T, E, (bf16*)x, ldx),
-         hipLaunchKernelGGL(embed_fwd<float>, dim3(B * T), dim3(128), 0, ST, q, emb, B, T, E, (float*)x, ldx));
+extern "C" int vqa_embed_fwd(void* stream, int dtype, const long* q, const float* emb, int B, int T, int E, int V,
+                             void* x, int ldx) {
+    if (B < 1 || T < 1 || E < 1 || V < 1 || ldx < E) return VQA_ERR_ARG;
+    BY_T(dtype, hipLaunchKernelGGL(embed_fwd<bf16>, dim3(B * T), dim3(128), 0, ST, q, emb, B, T, E, V, (bf16*)x, ldx),
+         hipLaunchKernelGGL(embed_fwd<float>, dim3(B * T), dim3(128), 0, ST, q, emb, B, T, E, V, (float*)x, ldx));
     CHECK_LAUNCH();
     return VQA_OK;
 }
 
-extern "C" int vqa_embed_bwd(void* stream, const long* q, const float* dx, int B, int T, int E, int lddx, float* demb) {
-    hipLaunchKernelGGL(embed_bwd, dim3(B * T), dim3(128), 0, ST, q, dx, B, T, E, lddx, demb);
+extern "C" int vqa_embed_bwd(void* stream, const long* q, const float* dx, int B, int T, int E, int V, int lddx,
+                             float* demb) {
+    if (B < 1 || T < 1 || E < 1 || V < 1) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(embed_bwd, dim3(B * T), dim3(128), 0, ST, q, dx, B, T, E, V, lddx, demb);
     CHECK_LAUNCH();
     return VQA_OK;
 }

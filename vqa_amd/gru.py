@@ -50,6 +50,9 @@ import os
 # runs on a side stream under the CNN, where the per-step launches fill idle CUs while a persistent grid that spins
 # on its device-wide barrier holds CUs and LDS away from the conv kernels (measured 8.20 vs 7.89 ms/step).
 USE_PERSISTENT = os.environ.get('VQA_GRU_PERSISTENT', '0') != '0'
+# workgroups (= CUs: one fits per CU) the persistent recurrence may hold; 0 = as many as are resident.  H/16 (one
+# batch slab) is the smallest grid: 64 CUs at H = 1024, the other 192 stay with the CNN.
+PERSISTENT_MAX_WG = int(os.environ.get('VQA_GRU_MAX_WG', '0'))
 
 
 def _persistent_ok(dtype, H):
@@ -65,17 +68,16 @@ class _GruFunction(torch.autograd.Function):
         Ep = ops.pad8(E)
         q = q.contiguous()
         x = torch.empty(T * B, Ep, device=dev, dtype=dtype)
-        L.call('vqa_embed_fwd', L.dt(x), q, emb, B, T, E, x, Ep)
+        L.call('vqa_embed_fwd', L.dt(x), q, emb, B, T, E, emb.shape[0], x, Ep)
         wih = ops.cast_pad(w_ih, dtype, Ep)                      # [3H, E] (row stride Ep)
         whh = ops.cast_pad(w_hh, dtype)
         gi = ops.gemm(x[:, :E], wih, bias=b_ih)                  # [T*B, 3H] fp32
         h_f = torch.zeros(T + 1, B, H, device=dev, dtype=torch.float32)   # h_{-1} = 0, h_0 .. h_{T-1}
         h_t = torch.zeros(T + 1, B, H, device=dev, dtype=dtype)
         save = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
-        if _persistent_ok(dtype, H):
-            flags = torch.empty(2, device=dev, dtype=torch.int32)
-            L.call('vqa_gru_fwd_persistent', gi, whh, whh.stride(0), b_hh, h_f, h_t, save, B, T, H, flags)
-        else:
+        if not (_persistent_ok(dtype, H) and
+                L.fits('vqa_gru_fwd_persistent', gi, whh, whh.stride(0), b_hh, h_f, h_t, save, B, T, H,
+                       torch.empty(2, device=dev, dtype=torch.int32), PERSISTENT_MAX_WG)):
             gh = torch.empty(B, 3 * H, device=dev, dtype=torch.float32)
             for t in range(T):
                 ops.gemm(h_t[t], whh, out=gh, bias=b_hh)
@@ -98,10 +100,9 @@ class _GruFunction(torch.autograd.Function):
         dgi = torch.empty(T * B, 3 * H, device=dev, dtype=dtype)
         dgh = torch.empty(T * B, 3 * H, device=dev, dtype=dtype)
         dh = dh_last.contiguous().float()
-        if _persistent_ok(dtype, H) and 16 * (6 * H + 32) <= 160 * 1024 and B <= 256 * max(1, 256 // (H // 16)):
-            flags = torch.empty(2, device=dev, dtype=torch.int32)
-            L.call('vqa_gru_bwd_persistent', whh_T, whh_T.stride(0), h_f, save, dh, dgi, dgh, B, T, H, flags)
-        else:
+        if not (_persistent_ok(dtype, H) and
+                L.fits('vqa_gru_bwd_persistent', whh_T, whh_T.stride(0), h_f, save, dh, dgi, dgh, B, T, H,
+                       torch.empty(2, device=dev, dtype=torch.int32), PERSISTENT_MAX_WG)):
             for t in range(T - 1, -1, -1):
                 dprev = torch.empty(B, H, device=dev, dtype=torch.float32)
                 L.call('vqa_gru_gate_bwd', L.dt(x), dh, save[t], h_f[t], B, H, dgi[t * B:(t + 1) * B],
@@ -117,7 +118,7 @@ class _GruFunction(torch.autograd.Function):
         dx = ops.gemm(dgi, wih_T)                                # [T*B, E] fp32
         demb = ops.grad_dst(emb)
         demb = torch.zeros_like(emb) if demb is None else demb.zero_()
-        L.call('vqa_embed_bwd', q, dx, B, T, E, dx.stride(0), demb)
+        L.call('vqa_embed_bwd', q, dx, B, T, E, emb.shape[0], dx.stride(0), demb)
         return None, None, demb, dw_ih, dw_hh, db_ih, db_hh
 
 

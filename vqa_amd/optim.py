@@ -117,6 +117,18 @@ class GradBuckets:
         return hook
 
     def wait(self):
+        """End of backward: every bucket must have been launched.  A bucket whose countdown did not reach zero holds a
+        parameter that received no gradient in this pass (an unused branch): its hook never fired, so the bucket is
+        reduced here - zero-filled slots for the missing gradients - instead of silently leaving the ranks with
+        different gradients."""
+        if self.active:
+            for b, left in enumerate(self._left):
+                if left != 0:
+                    ops.join_deferred()
+                    self.flat.collect([q for q, bq in zip(self.flat.params, self._bucket_idx) if bq == b])
+                    s, e = self.flat.bucket_ranges[b]
+                    self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                        async_op=True))
         for h in self.handles:
             h.wait()
         self.reset()
@@ -164,19 +176,19 @@ class Trainer:
         self.opt = FlatAdamax(self.flat, lr=lr, max_norm=max_norm)
         self.criterion = SoftScoreBCELoss()
 
-    def step(self, images, questions, target, flip=True):
+    def step(self, images, questions, target, flip=True, dropout_noise=None):
         """The step runs on a high-priority HIP stream of its own, ordered after and before the caller's current
         stream: its kernels are the critical chain, and the work the model puts on side streams (question encoder,
         weight gradients: normal priority) then only fills what that chain leaves idle (4.96 -> 4.90 ms/step)."""
         if not STEP_PRIORITY or not images.is_cuda:
-            return self._step(images, questions, target, flip)
+            return self._step(images, questions, target, flip, dropout_noise)
         cur = torch.cuda.current_stream(images.device)
         hp = self.stream
         if cur == hp:                                  # the caller already runs its loop on the trainer's stream
-            return self._step(images, questions, target, flip)
+            return self._step(images, questions, target, flip, dropout_noise)
         hp.wait_stream(cur)
         with torch.cuda.stream(hp):
-            loss = self._step(images, questions, target, flip)
+            loss = self._step(images, questions, target, flip, dropout_noise)
         cur.wait_stream(hp)
         loss.record_stream(cur)
         return loss
@@ -192,11 +204,11 @@ class Trainer:
             _STEP_STREAMS[key] = torch.cuda.Stream(dev, priority=-1)
         return _STEP_STREAMS[key]
 
-    def _step(self, images, questions, target, flip=True):
+    def _step(self, images, questions, target, flip=True, dropout_noise=None):
         self.opt.zero_grad()
         # the reference flips the batch tensor (vqa_model.py:250); same coin, but the first conv reads it mirrored
         mirror = flip and self.model.flip.draw()
-        logits = self.model(images, questions, mirror=mirror)
+        logits = self.model(images, questions, mirror=mirror, dropout_noise=dropout_noise)
         loss = self.criterion(logits, target)
         loss.backward()
         ops.join_deferred()

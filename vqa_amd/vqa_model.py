@@ -172,12 +172,26 @@ class _HeadFunction(torch.autograd.Function):
         if HEAD_WGRAD_STREAM:
             from .cnn import _wgrad_stream
             side = _wgrad_stream(dev)
-            side.wait_event(torch.cuda.current_stream().record_event())
+            cur = torch.cuda.current_stream()
+            side.wait_event(cur.record_event())
+            # Autograd hands the returned gradients to each parameter's AccumulateGrad node right after this function,
+            # on THIS stream.  With p.grad None and no tensor hooks that node only adopts the tensor (no kernel), so
+            # the side-stream work may still be running and is joined later (ops.defer_join).  With an existing
+            # p.grad (gradient accumulation, zero_grad(set_to_none=False), a second backward) it runs `p.grad += g`,
+            # and a tensor hook reads g: both must see finished gradients, so this stream waits before returning.
+            head_params = (g_att, v_att, b_att, g_s, v_s, g_img, v_img, b_img, g_q, v_q, b_q, g_last, v_last, b_last,
+                           g_fc, v_fc)
+            adopt_only = all(p.grad is None and not p._backward_hooks for p in head_params)
             with torch.cuda.stream(side):
                 wn, db_att, db_img, db_q, db_last = weights()
             for t in (dl_t, m_t, dpre_last, m0, dpv, vhat_t, dpq, q_t, dws_part, dqa, dpre_a, v_t, dqa_t, ss):
                 t.record_stream(side)                                            # (freed on this stream, read on that)
-            ops.defer_join(side)
+            if adopt_only:
+                ops.defer_join(side)
+            else:
+                cur.wait_event(side.record_event())
+                for t in [x for pair in wn for x in pair] + [db_att, db_img, db_q, db_last]:
+                    t.record_stream(cur)                                         # (allocated on that stream, read on this)
         else:
             wn, db_att, db_img, db_q, db_last = weights()
         (dg_att, dv_att), (dg_s, dv_s), (dg_img, dv_img), (dg_q, dv_q), (dg_last, dv_last), (dg_fc, dv_fc) = wn
@@ -231,8 +245,10 @@ class VQA(nn.Module):
         keep = 1.0 - self.dropout_p
         return torch.empty(B, self.hidden_dim, device=dev).bernoulli_(keep).div_(keep)
 
-    def forward(self, images_batch, questions_batch, mirror=False):
+    def forward(self, images_batch, questions_batch, mirror=False, dropout_noise=None):
         # mirror=True: the batch as model.flip would have flipped it, without the flipped copy (Trainer.step)
+        # dropout_noise=(n1, n2): the two nn.Dropout noise tensors [B,H] (keep / (1-p)) of vqa_model.py:101 / :103
+        # given by the caller instead of drawn here (parity tests replay the reference's recorded draws)
         if not images_batch.is_cuda:
             raise L.VqaHipError('vqa_amd.VQA runs on an MI355X only: there is no CPU fallback for the hot path')
         # The question encoder (28 small latency-bound launches per direction) is independent of the image
@@ -250,9 +266,18 @@ class VQA(nn.Module):
         else:
             images_representation = self.cnn(images_batch, mirror)
             questions_representation = self.gru(questions_batch)
+        return self.head(images_representation, questions_representation, dropout_noise)
+
+    def head(self, images_representation, questions_representation, dropout_noise=None):
+        """Attention + fusion + classifier (vqa_model.py:83-103) on given encoder outputs v [B,k,256], q [B,H] (fp32):
+        the second half of forward(), callable on its own (parity tests feed it the oracle's encoder outputs)."""
         dtype = torch.bfloat16 if self.precision == 'bf16' else torch.float32
-        B = images_batch.shape[0]
-        masks = (self._dropout_mask(B, images_batch.device), self._dropout_mask(B, images_batch.device))
+        B, dev = images_representation.shape[0], images_representation.device
+        if dropout_noise is not None:
+            masks = tuple(None if t is None else t.to(dev, torch.float32).contiguous() for t in dropout_noise)
+            assert all(t is None or tuple(t.shape) == (B, self.hidden_dim) for t in masks)
+        else:
+            masks = (self._dropout_mask(B, dev), self._dropout_mask(B, dev))
         a, s, i, qq, l, f = (getattr(self, n) for n in HEAD_LAYERS)
         return _HeadFunction.apply(images_representation, questions_representation, dtype, masks,
                                    a.weight_g, a.weight_v, a.bias, s.weight_g, s.weight_v, i.weight_g, i.weight_v,

@@ -10,7 +10,8 @@ from tests.helpers import CONFIGS, build_model, load_case, rel_err, sample_idx
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('name', list(CONFIGS))
+# (the B=32 case has its own, tighter test: tests/test_gpu_train_parity.py)
+@pytest.mark.parametrize('name', [n for n in CONFIGS if not n.endswith('_b32')])
 def test_fp32_model_vs_golden(name, tmp_path):
     """fp32 path: logits / loss <= 1e-4 relative of the reference; GRU/head gradients <= 2e-3 (weight_g: scalar sums
     with cancellation), CNN gradients within the ReLU/arg-max flip band (3e-2 at these tiny batches)."""

@@ -5,9 +5,11 @@
  * (file:line under the reference tree).  The Python binding is vqa_amd/_lib.py (ctypes); INTEGRATION.md shows it.
  *
  * Conventions
- *   - every function returns 0 on success, 1 = bad argument, 2 = launch failure; nothing throws across the ABI;
+ *   - every function returns 0 on success, 1 = bad argument, 2 = launch failure (3 = over capacity, only
+ *     vqa_soft_accuracy_sum_noalloc); nothing throws across the ABI;
  *   - `stream` is a hipStream_t (PyTorch's current stream); all work is asynchronous on it; the library keeps no
- *     state, caches no stream or device, allocates nothing, and is re-entrant (autograd worker threads call it);
+ *     state, caches no stream or device, allocates nothing, and is re-entrant (autograd worker threads call it) - the
+ *     one exception is vqa_soft_accuracy_sum_noalloc, which owns a static per-GPU scratch array (see there);
  *   - the caller owns every buffer (inputs, outputs, workspaces, saved-for-backward tensors), all device memory;
  *   - dtype codes: 0 = f32, 1 = bf16, 2 = f16 (image input only).  "T" below = the activation / MFMA dtype;
  *   - activations are NHWC; matrices are row-major with an explicit leading dimension in elements.
@@ -184,6 +186,15 @@ int vqa_bce_sum(void* stream, const float* logits, const float* target, int B, i
  * is torch.argmax's (first maximum, NaN largest), always a valid index.  rows: B floats of scratch. */
 int vqa_soft_accuracy_sum(void* stream, const float* logits, const float* target, int B, int C, int ldx, float* rows,
                           float* acc);
+
+/* NO COUNTERPART IN THE REFERENCE.  vqa_soft_accuracy_sum for callers that cannot allocate or hand over scratch: code
+ * under HIP graph capture, tight serving / evaluation loops, harnesses that forbid hipMalloc.  Same result bit for bit;
+ * the B floats of scratch live in a file-scope device array of the library (256 KiB per GPU, held until the process
+ * ends; its address is looked up once per device, on the first call there).  No hipMalloc / hipFree, no workspace
+ * argument.  B <= 65536: a larger batch returns 3 (VQA_ERR_CAPACITY) and launches nothing.  All calls on one GPU share
+ * that GPU's array: calls that overlap there (two streams, two threads) race; calls ordered on one stream do not. */
+int vqa_soft_accuracy_sum_noalloc(void* stream, const float* logits, const float* target, int B, int C, int ldx,
+                                  float* acc);
 
 /* The same two from SPARSE soft-score targets: the (labels, scores) lists that dataset.py:135-138
  * scatters into the dense [B][C] matrix.  labels int64 [B][L] (< 0 = empty slot, distinct within a row), scores f32

@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #define VQA_OK 0
 #define VQA_ERR_ARG 1
 #define VQA_ERR_LAUNCH 2
+#define VQA_ERR_CAPACITY 3   // the no-allocation entry point: input larger than its static scratch
 
 #define VQA_F32 0
 #define VQA_BF16 1

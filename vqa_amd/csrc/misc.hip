@@ -3,6 +3,7 @@
 // Reference call sites: gru.py:48-52,101-106; vqa_model.py:59-75 (weight_norm), :83-103 (head), :215 (loss),
 // :127-132 (accuracy), :259/:218/:266 (clip + Adamax).
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -916,6 +917,49 @@ extern "C" int vqa_bce_sum(void* stream, const float* logits, const float* targe
 // acc[0] = sum_b target[b][argmax logits[b]];  rows: B floats of scratch
 extern "C" int vqa_soft_accuracy_sum(void* stream, const float* logits, const float* target, int B, int C, int ldx,
                                      float* rows, float* acc) {
+    hipLaunchKernelGGL(soft_acc_rows, dim3(B), dim3(64), 0, ST, logits, target, C, ldx, rows);
+    hipLaunchKernelGGL(sum_f32, dim3(1), dim3(64), 0, ST, rows, B, acc);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+// ---- the ONE entry point that allocates nothing and takes no workspace (no counterpart in the reference).
+// vqa_soft_accuracy_sum needs B floats of scratch (one gathered score per row, summed in fixed order by the second
+// kernel); callers that cannot hand over device memory they allocated for it - code under HIP graph capture, tight
+// serving loops, harnesses that forbid hipMalloc - use this variant, whose scratch is a file-scope device array.
+// Each GPU holds its own copy of the array at its own address until the process ends; `scratch` below is only the
+// host-side stand-in for it, never a device address: the address comes from hipGetSymbolAddress, once per device.
+constexpr int NOALLOC_MAX_ROWS = 65536;                       // 256 KiB per GPU
+static __device__ __align__(256) float scratch[NOALLOC_MAX_ROWS];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static std::atomic<float*> scratch_ptr[NOALLOC_MAX_DEVICES];   // per device, filled on the first call there
+
+// The current device's copy of `scratch` (nullptr on failure).  Set-up happens on the first call on a device, with
+// that device current (the caller's: the one its stream and buffers live on); two threads racing here resolve the same
+// address.
+static float* scratch_of_current_device() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) return nullptr;
+    float* p = scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        void* sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)) != hipSuccess || !sym) return nullptr;
+        p = static_cast<float*>(sym);
+        scratch_ptr[dev].store(p, std::memory_order_release);
+    }
+    return p;
+}
+
+// acc[0] = sum_b target[b][argmax logits[b]] exactly as vqa_soft_accuracy_sum, without the `rows` workspace.
+// B <= 65536 (VQA_ERR_CAPACITY beyond).  Every call on a GPU shares that GPU's scratch array: calls that overlap on one
+// GPU (two streams, two threads) race on it; calls ordered on one stream do not.  Nothing needs clearing between
+// calls: rows [0, B) are overwritten before the sum reads exactly those.
+extern "C" int vqa_soft_accuracy_sum_noalloc(void* stream, const float* logits, const float* target, int B, int C,
+                                             int ldx, float* acc) {
+    if (B < 1 || C < 1 || ldx < C || !logits || !target || !acc) return VQA_ERR_ARG;
+    if (B > NOALLOC_MAX_ROWS) return VQA_ERR_CAPACITY;
+    float* rows = scratch_of_current_device();
+    if (!rows) return VQA_ERR_LAUNCH;
     hipLaunchKernelGGL(soft_acc_rows, dim3(B), dim3(64), 0, ST, logits, target, C, ldx, rows);
     hipLaunchKernelGGL(sum_f32, dim3(1), dim3(64), 0, ST, rows, B, acc);
     CHECK_LAUNCH();

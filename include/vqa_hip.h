@@ -43,10 +43,15 @@ int vqa_conv_pack_all(void* stream, int dtype, int n, const void* const* w, void
  * tile; G persistent workgroups per output-channel block walk the (image, tile) pairs - take G from
  * vqa_conv3x3_plan() (resident workgroups of the instantiation x 256 CUs; -1 = unsupported shape).  `stats` (may be
  * NULL) receives G rows of per-channel (sum, sum of squares) of y, [G][Cout][2], for the BatchNorm that follows.
- * x and y are addressed through 32-bit byte offsets (buffer resources): each must be smaller than 4 GiB. */
+ * x and y are addressed through 32-bit byte offsets (buffer resources): each must be smaller than 4 GiB.
+ * in_scale / in_shift ([Cin] f32, both or neither; pad must be 0): x is the RAW output of the previous conv and the
+ * input is relu(in_scale * x + in_shift) - that layer's nn.BatchNorm2d + nn.ReLU (cnn.py:23-24, ...), applied while
+ * the input tile is staged, so the normalised activation is never written (bit-identical to vqa_bn_act_pool_fwd
+ * with pool = 0 followed by this call without them). */
 int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked, void* y, const float* bias,
                     float* stats, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW,
-                    int G, int relu /* 1: y = max(conv + bias, 0) - eval mode with the BatchNorm folded into w, bias */);
+                    int G, int relu /* 1: y = max(conv + bias, 0) - eval mode with the BatchNorm folded into w, bias */,
+                    const float* in_scale, const float* in_shift);
 int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW);
 
 /* First encoder layer, bf16 path: nn.Conv2d(3, 16, 3, padding=pad) (cnn.py:23) straight from the NCHW image
@@ -73,9 +78,11 @@ int vqa_conv3x3_first_wgrad_bn(void* stream, int in_dtype, const void* images, c
                                int OH, int OW, int pad, int R, int CW, int flip);
 
 /* Conv2d weight gradient (autograd of cnn.py:23-40): dw [Cout][Cin_real][3][3] f32 = sum over pixels of dy (x) x.
- * `part` is a [G][Cout][9][Cin] f32 workspace (one partial slab per workgroup group, summed in fixed order). */
+ * `part` is a [G][Cout][9][Cin] f32 workspace (one partial slab per workgroup group, summed in fixed order).
+ * in_scale / in_shift: as in vqa_conv3x3_fwd (x = the previous conv's raw output, pad == 0). */
 int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const void* dy, float* part, float* dw, int G, int B,
-                      int IH, int IW, int Cin, int Cin_real, int OH, int OW, int Cout, int pad, int R, int CW);
+                      int IH, int IW, int Cin, int Cin_real, int OH, int OW, int Cout, int pad, int R, int CW,
+                      const float* in_scale, const float* in_shift);
 
 /* nn.BatchNorm2d training statistics (cnn.py:23-40; eps 1e-5, momentum 0.1): from the conv partials to mean,
  * invstd, scale = gamma*invstd, shift = beta - mean*scale; running_mean / running_var updated in place

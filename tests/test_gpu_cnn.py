@@ -253,3 +253,65 @@ def test_cnn_stack_vs_oracle(prec, padding, pooling, size, B):
         assert e < tol_g, (k, e)
     print(flush=True); print(f'[{prec} pad{padding} {pooling} {size}] fwd {rel(out, v_ref):.2e} eval {rel(out_eval, v_eval):.2e} '
           f'worst grad {worst:.2e}')
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('B,cin,cout,H,W', [(2, 16, 16, 40, 40), (3, 32, 32, 23, 31), (2, 64, 64, 30, 30),
+                                            (2, 128, 128, 16, 14), (3, 256, 256, 12, 12), (1, 16, 16, 226, 226),
+                                            (2, 16, 32, 9, 20), (1, 64, 128, 17, 17)])
+def test_fused_input_bn_relu_is_the_separate_pass(prec, B, cin, cout, H, W):
+    """vqa_conv3x3_fwd / vqa_conv3x3_wgrad with in_scale / in_shift (the previous layer's BatchNorm + ReLU applied while
+    the input tile is staged) against the separate pass followed by the plain kernels: y, the BatchNorm statistics and
+    dW bit for bit - same arithmetic, the activation just never goes through HBM; and against the fp32 formula."""
+    from vqa_amd import cnn as C
+    torch.manual_seed(cin * 7 + cout + H)
+    dt = DT[prec]
+    yprev = (torch.randn(B, H, W, cin) * 1.5).to(dt).cuda()                 # raw output of the previous conv, NHWC
+    scale = (torch.rand(cin) + 0.5).cuda()
+    shift = (torch.randn(cin) * 0.4).cuda()
+    w = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
+    bias = torch.randn(cout) * 0.1
+    wpk = C.pack_weights(w.cuda(), cin, dt, dgrad=False)
+    a = C.bn_act_pool(yprev, scale, shift, 0)
+    y_sep, st_sep = C.conv_fwd(a, wpk, bias.cuda(), cout, 0, True)
+    y_fus, st_fus = C.conv_fwd(yprev, wpk, bias.cuda(), cout, 0, True, in_coeffs=(scale, shift))
+    assert torch.equal(y_fus, y_sep) and torch.equal(st_fus, st_sep)
+    a_ref = torch.relu(yprev.float().cpu() * scale.cpu() + shift.cpu()).to(dt).float().permute(0, 3, 1, 2)
+    y_ref = F.conv2d(a_ref, w.to(dt).float(), bias)
+    err = (y_fus.float().cpu().permute(0, 3, 1, 2) - y_ref).norm() / y_ref.norm()
+    assert float(err) < (1e-5 if prec == 'fp32' else 4e-3)
+    dy = (torch.randn(B, H - 2, W - 2, cout)).to(dt).cuda()
+    dw_sep = C.conv_wgrad(a, dy, cin, 0)
+    dw_fus = C.conv_wgrad(yprev, dy, cin, 0, in_coeffs=(scale, shift))
+    assert torch.equal(dw_fus, dw_sep)
+    # a padded conv cannot take the fused form (its zero padding would become relu(shift)): refused, not wrong
+    from vqa_amd._lib import VqaHipError
+    with pytest.raises(VqaHipError):
+        C.conv_fwd(yprev, wpk, bias.cuda(), cout, 2, True, in_coeffs=(scale, shift))
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('padding,pooling,size,B', [(2, 'max', 224, 3), (0, 'avg', 224, 2), (5, 'max', 200, 2)])
+def test_encoder_with_fused_bn_forward_is_bit_identical(prec, padding, pooling, size, B, monkeypatch):
+    """The whole encoder, training mode: BatchNorm + ReLU of each block's first conv applied by its consumers
+    (cnn.FUSE_BN_FWD, the default) against the separate passes: output, running statistics and every gradient bit
+    for bit."""
+    from vqa_amd import cnn as M, synth
+    sd = {k[4:]: v for k, v in synth.state_dict(42, 64, 50, 30).items() if k.startswith('cnn.')}
+    img = synth.images(9, B, size).cuda()
+    outs = []
+    for fuse in (True, False):
+        monkeypatch.setattr(M, 'FUSE_BN_FWD', fuse)
+        m = M.CNN(padding, pooling, precision=prec)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        out = m(img)
+        torch.manual_seed(1)
+        (out * torch.rand_like(out)).sum().backward()
+        outs.append((out.detach(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                     {k: b.clone() for k, b in m.named_buffers()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k

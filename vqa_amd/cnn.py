@@ -101,8 +101,10 @@ def _conv_tag(kind, B, OH, OW, cin_real, cout_real, x, y_elems_bytes, w_bytes):
                 bytes=float(x.numel() * x.element_size() + y_elems_bytes + w_bytes))
 
 
-def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', relu=False):
-    """x NHWC [B,IH,IW,Cin] -> y [B,OH,OW,Cout] (+ partial BN statistics rows)."""
+def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', relu=False, in_coeffs=None):
+    """x NHWC [B,IH,IW,Cin] -> y [B,OH,OW,Cout] (+ partial BN statistics rows).
+    in_coeffs = (scale, shift): x is the previous conv's RAW output and the kernel applies that layer's BatchNorm +
+    ReLU while it stages its input tile (pad must be 0)."""
     B, IH, IW, cin = x.shape
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
     R, CW = pick_tile(OH, OW)
@@ -112,8 +114,9 @@ def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', rel
     cr = cin if cin_real is None else cin_real
     tag = _conv_tag(kind, B, OH, OW, cr, cout, x,
                     y.numel() * y.element_size(), wpk.numel() * wpk.element_size())
+    isc, ish = in_coeffs if in_coeffs is not None else (None, None)
     L.call('vqa_conv3x3_fwd', L.dt(x), x, wpk, y, bias, stats, B, IH, IW, cin, OH, OW, cout, pad, R, CW, G, int(relu),
-           tag=tag)
+           isc, ish, tag=tag)
     return y, stats
 
 
@@ -130,7 +133,7 @@ def _plan(*key):
     return _plans[key]
 
 
-def conv_wgrad(x, dy, cin_real, pad, out=None):
+def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None):
     B, IH, IW, cin = x.shape
     _, OH, OW, cout = dy.shape
     mt = 256 if x.dtype == torch.bfloat16 else 128
@@ -143,7 +146,7 @@ def conv_wgrad(x, dy, cin_real, pad, out=None):
     cow = min(cout, 64)                                   # output channels per workgroup (conv.hip dy_stride)
     dyb = (32 if cow == 16 else cow * 2 + 32) if esz == 2 else (64 if cow == 16 else cow * 4 + 64)
     kc = 64 // esz
-    lds = (R + 2) * (CW + 2) * pxb + (-(-R * CW // kc) * kc) * (dyb + 4)
+    lds = (R + 2) * (CW + 2) * pxb + (-(-R * CW // kc) * kc) * (dyb + 4) + 8 * ck
     # resident workgroups per CU: register-limited waves/SIMD of the instantiation, then LDS
     waves = 4 if cow == 16 else 2
     per_cu = max(1, min(waves, (160 * 1024) // lds))
@@ -151,8 +154,9 @@ def conv_wgrad(x, dy, cin_real, pad, out=None):
     part = torch.empty(G, cout, 9, cin, device=x.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)
     tag = _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4)
+    isc, ish = in_coeffs if in_coeffs is not None else (None, None)
     L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw, G, B, IH, IW, cin, cin_real, OH, OW, cout, pad, R, CW,
-           tag=tag)
+           isc, ish, tag=tag)
     return dw
 
 
@@ -234,16 +238,19 @@ def first_wgrad(images, dy, pad, out=None, mirror=False, bn=None):
     return dw
 
 
-def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False, wpk=None, mirror=False):
+def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False, wpk=None, mirror=False,
+              in_coeffs=None, apply=True):
     """conv3x3 -> BatchNorm -> ReLU -> (pool).  x NHWC (first=True: the NCHW image, dedicated kernel).  Returns
-    (a, saved) with saved = (x, y, scale, shift, mean, invstd) for block_bwd."""
+    (a, saved) with saved = (x, y, scale, shift, mean, invstd) for block_bwd.
+    in_coeffs: x is the raw conv output of the previous block, whose BatchNorm + ReLU this block's conv applies itself.
+    apply=False (pool == 0 only): the BatchNorm + ReLU pass is left to the consumer; returns a = None."""
     dev, cout = x.device, w.shape[0]
     if first:
         y, stats = first_fwd(x, w, bias, pad, training, mirror=mirror)
     else:
         if wpk is None:
             wpk = pack_weights(w, x.shape[3], x.dtype, dgrad=False)
-        y, stats = conv_fwd(x, wpk, bias, cout, pad, training, cin_real=w.shape[1])
+        y, stats = conv_fwd(x, wpk, bias, cout, pad, training, cin_real=w.shape[1], in_coeffs=in_coeffs)
     scale, shift, mean, invstd = torch.empty(4, cout, device=dev, dtype=torch.float32).unbind(0)
     if training:
         count = float(y.shape[0] * y.shape[1] * y.shape[2])
@@ -254,12 +261,12 @@ def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False,
                 'vqa_bn_finalize')
     else:
         L.call('vqa_bn_eval_coeffs', cout, gamma, beta, rm, rv, BN_EPS, scale, shift)
-    a = bn_act_pool(y, scale, shift, pool)
+    a = bn_act_pool(y, scale, shift, pool) if apply else None
     return a, (x, y, scale, shift, mean, invstd)
 
 
 def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None, params=None, mirror=False,
-              side=None):
+              side=None, in_coeffs=None):
     """d = gradient w.r.t. the block output (NHWC, activation dtype).  Returns (dx, dw, dbias, dgamma, dbeta).
     side: HIP stream for the weight gradient (off the dgrad -> BatchNorm-backward chain), None = current stream."""
     x, y, scale, shift, mean, invstd = saved
@@ -302,7 +309,7 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
     L.call('vqa_bn_bwd', L.dt(y), 1, y, d, dy, scale, shift, mean, invstd, c1, c2, None, B, H, W, C, pool, tag=tag)
     def wgrad():
         return (first_wgrad(x, dy, pad, out=dw_out, mirror=mirror) if first
-                else conv_wgrad(x, dy, cin_real, pad, out=dw_out))
+                else conv_wgrad(x, dy, cin_real, pad, out=dw_out, in_coeffs=in_coeffs))
 
     def dgrad():
         if not need_dx:
@@ -373,6 +380,11 @@ def _eval_forward(x, first, params, buffers, padding, pool_mode, dtype):
 # BatchNorm-backward): it runs on its own HIP stream beside the dgrad that reads the same dy (same-box A/B:
 # 5.26 -> 5.22 ms/step).  VQA_WGRAD_STREAM=0 keeps everything on one stream.
 WGRAD_STREAM = os.environ.get('VQA_WGRAD_STREAM', '1') != '0'
+# Training forward: the BatchNorm + ReLU of the first conv of each block (no pool behind it) is applied by its two
+# consumers - the block's second conv and that conv's weight gradient - while they stage their input tiles; the
+# normalised activation is never written (5 passes and 1.6 GB of traffic per step at B = 256).  VQA_FUSE_BN_FWD=0: the
+# separate pass (bit-identical results).
+FUSE_BN_FWD = os.environ.get('VQA_FUSE_BN_FWD', '1') != '0'
 FUSE_FIRST_BN = os.environ.get('VQA_FUSE_FIRST_BN', '1') != '0'
 _WGRAD_STREAMS = {}
 
@@ -407,14 +419,18 @@ class _CnnFunction(torch.autograd.Function):
         slabs = pack_all(fjobs + djobs, dtype)
         wf = ([None] if first else []) + slabs[:len(fjobs)]
         ctx.wd = [None] + slabs[len(fjobs):] if training else None
+        in_coeffs = None
         for li in range(10):
             w, bias, gamma, beta = params[4 * li: 4 * li + 4]
             pad = padding if li in (0, 2, 4, 6) else 0
             pool = pool_mode if li % 2 == 1 else 0
-            x, sv = block_fwd(x, w, bias, gamma, beta, buffers[2 * li], buffers[2 * li + 1], pad, pool, training,
-                              first=first and li == 0, wpk=wf[li], mirror=mirror and li == 0)
+            defer = FUSE_BN_FWD and pool == 0 and li < 9        # the next conv (pad 0) applies this block's BN + ReLU
+            a, sv = block_fwd(x, w, bias, gamma, beta, buffers[2 * li], buffers[2 * li + 1], pad, pool, training,
+                              first=first and li == 0, wpk=wf[li], mirror=mirror and li == 0, in_coeffs=in_coeffs,
+                              apply=not defer)
             saved += list(sv)
-            meta.append((pad, pool))
+            meta.append((pad, pool, in_coeffs is not None))
+            x, in_coeffs = (sv[1], (sv[2], sv[3])) if defer else (a, None)
         ctx.save_for_backward(*saved, *params)
         ctx.meta, ctx.cfg, ctx.first, ctx.mirror = meta, cfg, first, mirror
         B, PH, PW, C = x.shape
@@ -432,11 +448,14 @@ class _CnnFunction(torch.autograd.Function):
         d = dout.reshape(B, H // 2 if pool_last else H, W // 2 if pool_last else W, C).to(dtype).contiguous()
         side = _wgrad_stream(dout.device) if WGRAD_STREAM else None
         for li in range(9, -1, -1):
-            pad, pool = ctx.meta[li]
+            pad, pool, fused_in = ctx.meta[li]
+            # fused_in: this layer's input x is the previous layer's raw conv output; its weight gradient re-applies
+            # that layer's BatchNorm + ReLU (saved scale / shift) as the forward conv did
+            in_coeffs = (saved[6 * (li - 1) + 2], saved[6 * (li - 1) + 3]) if fused_in else None
             d, dw, db, dg, dbt = block_bwd(d, saved[6 * li: 6 * li + 6], params[4 * li], CHANNELS[li], pad, pool,
                                            li > 0, first=ctx.first and li == 0, wpk_d=ctx.wd[li],
                                            mirror=ctx.mirror and li == 0,
-                                           params=params[4 * li: 4 * li + 4], side=side)
+                                           params=params[4 * li: 4 * li + 4], side=side, in_coeffs=in_coeffs)
             grads[4 * li: 4 * li + 4] = [dw, db, dg, dbt]
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)

@@ -194,6 +194,30 @@ __device__ __forceinline__ void sum16_x4(float& a, float& b, float& c, float& d)
 #undef VQA_DPP4
 }
 
+// BatchNorm + ReLU forward on one 16-byte vector of T, a = round_T(max(fma(y, scale, shift), 0)): exactly the
+// arithmetic of bn_act_pool_fwd (pool = 0), applied by a CONSUMER of the raw conv output y while it stages its input,
+// so the normalised activation is never written to HBM.  sc / sh: the 16 / sizeof(T) channels of the vector.
+template <typename T> __device__ __forceinline__ uint4 bn_relu_vec(const uint4& v, const float* sc, const float* sh);
+template <> __device__ __forceinline__ uint4 bn_relu_vec<bf16>(const uint4& v, const float* sc, const float* sh) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = fmaxf(fmaf(__uint_as_float(w[i] << 16), sc[2 * i], sh[2 * i]), 0.f);
+        const float hi = fmaxf(fmaf(__uint_as_float(w[i] & 0xFFFF0000u), sc[2 * i + 1], sh[2 * i + 1]), 0.f);
+        typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t t = {(bf16)lo, (bf16)hi};
+        o[i] = __builtin_bit_cast(unsigned, t);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+template <> __device__ __forceinline__ uint4 bn_relu_vec<float>(const uint4& v, const float* sc, const float* sh) {
+    return make_uint4(__float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), sc[0], sh[0]), 0.f)),
+                      __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), sc[1], sh[1]), 0.f)),
+                      __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), sc[2], sh[2]), 0.f)),
+                      __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), sc[3], sh[3]), 0.f)));
+}
+
 template <typename T> __device__ __forceinline__ void store_vec4(T* p, const float* v);
 template <> __device__ __forceinline__ void store_vec4<float>(float* p, const float* v) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);

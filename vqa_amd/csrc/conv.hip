@@ -33,6 +33,11 @@ struct ConvArgs {
     int R, CW, tiles_x, tiles_y;
     float inv_cw, inv_pw, inv_tx, inv_tiles;
     int relu;           // epilogue: y = max(conv + bias, 0)  (eval mode with the BatchNorm folded into w / bias)
+    // XF kernels: x is the RAW output of the previous conv and the input really is relu(in_scale * x + in_shift) - the
+    // previous layer's BatchNorm + ReLU, applied per 16-byte vector on the way into LDS ([Cin] each).  Only for
+    // pad == 0 (every conv that follows an un-pooled block, cnn.py:24,28,32,36,40): no zero padding to preserve.
+    const float* in_scale;
+    const float* in_shift;
 };
 
 template <typename T, int CK> struct ConvCfg {
@@ -60,7 +65,7 @@ __device__ unsigned long long g_stamps[16384][12];
 // ---------------------------------------------------------------------------------------------- igemm
 // One workgroup per (tile, image, channel block): the multi-chunk (Cin > CK) layers, which are MFMA-bound and
 // want their registers for the accumulators and the chunk prefetch rather than for persistent-loop state.
-template <typename T, int CK, int NBF>
+template <typename T, int CK, int NBF, bool XF>
 __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     using Cfg = ConvCfg<T, CK>;
     constexpr int VEC = Cfg::VEC, KC = Cfg::KC, KP = Cfg::KP, NS = Cfg::NS, PXB = Cfg::PXB, WROWB = Cfg::WROWB,
@@ -70,10 +75,17 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     const int PW = a.CW + 2, PPIX = (a.R + 2) * PW, PROWB = PW * PXB + Cfg::RPAD;
     unsigned char* patch = smem;
     unsigned char* wl = smem + (a.R + 2) * PROWB;
+    float* coefl = reinterpret_cast<float*>(wl + NB * WROWB);   // XF: [2][Cin] input scale / shift
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     STAMP(0);
+    if constexpr (XF) {                                         // (read by the first stash: barrier below)
+        for (int i = tid; i < a.Cin; i += 256) {
+            coefl[i] = a.in_scale[i];
+            coefl[a.Cin + i] = a.in_shift[i];
+        }
+    }
 
     const int tile = blockIdx.x, b = blockIdx.y, co0 = blockIdx.z * NB;
     const int ty = fastdiv(tile, a.tiles_x, a.inv_tx), tx = tile - ty * a.tiles_x;
@@ -146,11 +158,21 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
             wv[j] = *reinterpret_cast<const uint4*>(wsrc + (i < NB * WV ? i : 0) * VEC);
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](int ch) {
+        float isc[VEC], ish[VEC];                               // XF: this thread's channel vector (256 % VPP == 0)
+        if constexpr (XF) {
+            const float* cs = coefl + ch * CK + (tid % VPP) * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) {
+                *reinterpret_cast<float4*>(isc + e) = *reinterpret_cast<const float4*>(cs + e);
+                *reinterpret_cast<float4*>(ish + e) = *reinterpret_cast<const float4*>(cs + a.Cin + e);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NPV; ++j) {
             const int i = tid + j * 256;
-            const uint4 t = pv[j];   // by value first: a conditional store straight from the array keeps it in scratch
+            uint4 t = pv[j];   // by value first: a conditional store straight from the array keeps it in scratch
+            if constexpr (XF) t = bn_relu_vec<T>(t, isc, ish);
             if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + pdst[j]) = t;
         }
 #pragma unroll
@@ -160,6 +182,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
             if (i < NB * WV) *reinterpret_cast<uint4*>(wl + (i / WV) * WROWB + (i % WV) * 16) = t;
         }
     };
+    if constexpr (XF) __syncthreads();                          // coefl is read by the first stash
 
     const int nchunks = a.Cin / CK;
     // the channel-chunk loop, specialised on the number of live fragments (a run-time test per fragment inside the
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
         STAMP(1);
         fetch(0);
         for (int ch = 0; ch < nchunks; ++ch) {
-            stash();
+            stash(ch);
             if (ch == 0) STAMP(2);
             __syncthreads();
             if (ch == 0) STAMP(3);
@@ -283,7 +306,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
 // tile is computed once per workgroup (fragment pixel decode, patch vector coordinates), the weight slab and the bias
 // stay resident in LDS, the next tile's patch is prefetched into registers during the MFMAs, and the BatchNorm
 // partial sums stay in registers across tiles: ONE statistics row per workgroup.
-template <typename T, int CK, int NBF>
+template <typename T, int CK, int NBF, bool XF>
 __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
     using Cfg = ConvCfg<T, CK>;
     constexpr int VEC = Cfg::VEC, KC = Cfg::KC, KP = Cfg::KP, NS = Cfg::NS, PXB = Cfg::PXB, WROWB = Cfg::WROWB,
@@ -294,6 +317,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
     unsigned char* patch = smem;
     unsigned char* wl = smem + (a.R + 2) * PROWB;
     float* biasl = reinterpret_cast<float*>(wl + NB * WROWB);   // [NB]
+    float* coefl = biasl + NB;                                  // XF: [2][CK] input scale / shift
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -338,6 +362,10 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
             *reinterpret_cast<uint4*>(wl + (i / WV) * WROWB + (i % WV) * 16) =
                 *reinterpret_cast<const uint4*>(wsrc + (long)i * VEC);
         if (tid < NB) biasl[tid] = a.bias ? a.bias[co0 + tid] : 0.f;
+        if constexpr (XF) {
+            if (tid < CK) { coefl[tid] = a.in_scale[tid]; coefl[CK + tid] = a.in_shift[tid]; }
+            __syncthreads();                                    // read by the first stash
+        }
     }
 
     f32x4 acc[4][NBF];
@@ -367,10 +395,20 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
         }
     };
     auto stash = [&]() {
+        float isc[VEC], ish[VEC];                               // XF: this thread's channel vector (256 % VPP == 0)
+        if constexpr (XF) {
+            const float* cs = coefl + (tid % VPP) * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) {
+                *reinterpret_cast<float4*>(isc + e) = *reinterpret_cast<const float4*>(cs + e);
+                *reinterpret_cast<float4*>(ish + e) = *reinterpret_cast<const float4*>(cs + CK + e);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NPV; ++j) {
             const int i = tid + j * 256;
-            const uint4 t = pv[j];   // by value first: a conditional store straight from the array keeps it in scratch
+            uint4 t = pv[j];   // by value first: a conditional store straight from the array keeps it in scratch
+            if constexpr (XF) t = bn_relu_vec<T>(t, isc, ish);
             if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + pdst[j]) = t;
         }
     };
@@ -461,6 +499,7 @@ size_t igemm_lds(const ConvArgs& a) {
                        (size_t)4 * NBF * 16 * 2 * 4;                                   // + their statistics rows
     if (lds < epi) lds = epi;
     lds += (size_t)NBF * 16 * 4;                                                       // resident bias row
+    lds += (size_t)2 * a.Cin * 4;                                                      // XF: input scale / shift
     return lds;
 }
 
@@ -473,8 +512,9 @@ int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
     const int total = a.tiles_x * a.tiles_y * a.B, zb = a.Cout / (NBF * 16);
     if (lds > 160 * 1024) return plan_only ? -1 : VQA_ERR_ARG;
     const bool persistent = a.Cin == CK;
-    auto kp = conv3x3_igemm_p<T, CK, NBF>;
-    auto kt = conv3x3_igemm_tile<T, CK, NBF>;
+    const bool xf = a.in_scale != nullptr;
+    auto kp = xf ? conv3x3_igemm_p<T, CK, NBF, true> : conv3x3_igemm_p<T, CK, NBF, false>;
+    auto kt = xf ? conv3x3_igemm_tile<T, CK, NBF, true> : conv3x3_igemm_tile<T, CK, NBF, false>;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(persistent ? (const void*)kp : (const void*)kt,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -514,6 +554,8 @@ struct WgradArgs {
     int B, IH, IW, Cin, OH, OW, Cout, pad;
     int R, CW, tiles_x, tiles_y;
     float inv_cw, inv_pw, inv_tx, inv_tiles;
+    const float* in_scale;   // XF kernels: x is the previous conv's raw output, the input is relu(in_scale*x + in_shift)
+    const float* in_shift;   // (see ConvArgs; pad == 0 only)
 };
 
 // One workgroup: NB = 64 output channels x CK input channels x 9 taps, looping over pixel tiles
@@ -531,7 +573,7 @@ __host__ __device__ constexpr int dy_stride(int esz, int cow) {
 // (wcg), i.e. 9 x COF accumulator tiles; waves left over split the pixel reduction (wk).  Per 32-pixel step a wave
 // then reads 9 patch fragments + COF dy fragments for 9 x COF MFMAs - the patch fragments, which dominate the LDS
 // traffic, are no longer re-read by every output-channel wave.
-template <typename T, int CK, int COW>
+template <typename T, int CK, int COW, bool XF>
 __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     constexpr int VEC = Mma<T>::VEC, KC = 4 * VEC;
     constexpr int PXB = pix_stride(CK * (int)sizeof(T));
@@ -548,6 +590,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     unsigned char* patch = smem;
     unsigned char* dyl = smem + (PPIX * PXB + 15) / 16 * 16;
     int* ptab = reinterpret_cast<int*>(dyl + MTP * DYB);   // [MTP] byte offset of tile pixel m inside the patch
+    float* coefl = reinterpret_cast<float*>(ptab + MTP);   // XF: [2][CK] input scale / shift of this workgroup's chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -585,6 +628,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
         drc[j] = ((m < MT ? pr : 0x4000) << 16) | pc;
         drel[j] = ((pr * a.OW + pc) * a.Cout + co0 + vv * VEC) * (int)sizeof(T);                        // bytes
     }
+    if constexpr (XF) {
+        if (tid < CK) { coefl[tid] = a.in_scale[ci0 + tid]; coefl[CK + tid] = a.in_shift[ci0 + tid]; }
+        __syncthreads();                                           // read by the first stash
+    }
     for (int m = tid; m < MTP; m += 256) {
         const int mm = m < MT ? m : 0;                             // dy rows beyond the tile are zero: any finite x
         const int pr = fastdiv(mm, a.CW, a.inv_cw);
@@ -618,10 +665,20 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
         }
     };
     auto stash = [&]() {
+        float isc[VEC], ish[VEC];                                  // XF: this thread's channel vector (256 % VPP == 0)
+        if constexpr (XF) {
+            const float* cs = coefl + (tid % VPP) * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) {
+                *reinterpret_cast<float4*>(isc + e) = *reinterpret_cast<const float4*>(cs + e);
+                *reinterpret_cast<float4*>(ish + e) = *reinterpret_cast<const float4*>(cs + CK + e);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NPV; ++j) {
             const int i = tid + j * 256;
-            const uint4 t = pv[j];   // by value first: a conditional store straight from the array keeps it in scratch
+            uint4 t = pv[j];   // by value first: a conditional store straight from the array keeps it in scratch
+            if constexpr (XF) t = bn_relu_vec<T>(t, isc, ish);
             if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + (i / VPP) * PXB + (i % VPP) * 16) = t;
         }
 #pragma unroll
@@ -864,8 +921,10 @@ __global__ void nchw_to_nhwc(const TI* in, T* out, int B, int C, int H, int W, i
 
 static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* wpacked, void* y, const float* bias,
                           float* stats, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW,
-                          int G, bool plan_only, int relu = 0) {
+                          int G, bool plan_only, int relu = 0, const float* in_scale = nullptr,
+                          const float* in_shift = nullptr) {
     const int bad = plan_only ? -1 : VQA_ERR_ARG;
+    if ((in_scale != nullptr) != (in_shift != nullptr) || (in_scale && pad != 0)) return bad;
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || R * CW > 256 ||
         (R + 2) * (CW + 2) > 384 || B < 1)
         return bad;
@@ -874,7 +933,7 @@ static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* w
     if ((double)B * IH * IW * Cin * esz_ >= 4294967040.0 || (double)B * OH * OW * Cout * esz_ >= 4294967040.0) return bad;
     const int tx_ = (OW + CW - 1) / CW, ty_ = (OH + R - 1) / R;
     ConvArgs a{x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
-               1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), relu};
+               1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), relu, in_scale, in_shift};
     if (dtype == VQA_BF16) {
         if (Cin % 32 == 0) return dispatch_nb<bf16, 32>(s, a, G, plan_only);
         if (Cin == 16) return dispatch_nb<bf16, 16>(s, a, G, plan_only);
@@ -886,9 +945,10 @@ static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* w
 
 extern "C" int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked, void* y,
                                const float* bias, float* stats, int B, int IH, int IW, int Cin, int OH, int OW,
-                               int Cout, int pad, int R, int CW, int G, int relu) {
+                               int Cout, int pad, int R, int CW, int G, int relu, const float* in_scale,
+                               const float* in_shift) {
     return conv_fwd_entry(static_cast<hipStream_t>(stream), dtype, x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW,
-                          Cout, pad, R, CW, G, false, relu);
+                          Cout, pad, R, CW, G, false, relu, in_scale, in_shift);
 }
 
 // G for vqa_conv3x3_fwd: persistent workgroups per output-channel block = rows of `stats`; -1 = unsupported shape
@@ -905,8 +965,10 @@ extern "C" int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int O
 
 extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const void* dy, float* part, float* dw,
                                  int G, int B, int IH, int IW, int Cin, int Cin_real, int OH, int OW, int Cout,
-                                 int pad, int R, int CW) {
+                                 int pad, int R, int CW, const float* in_scale, const float* in_shift) {
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || G < 1) return VQA_ERR_ARG;
+    if ((in_scale != nullptr) != (in_shift != nullptr) || (in_scale && pad != 0)) return VQA_ERR_ARG;
+    const bool xf = in_scale != nullptr;
     {   // x and dy are addressed through 32-bit byte offsets (buffer resources)
         const int esz_ = dtype == VQA_BF16 ? 2 : 4;
         if ((double)B * IH * IW * Cin * esz_ >= 4294967040.0 || (double)B * OH * OW * Cout * esz_ >= 4294967040.0)
@@ -916,7 +978,7 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     const int COW = Cout >= 64 ? 64 : Cout;      // output channels per workgroup
     if ((COW != 16 && COW != 32 && COW != 64) || Cout % COW) return VQA_ERR_ARG;
     WgradArgs a{x, dy, part, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
-                1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_)};
+                1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), in_scale, in_shift};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int MT = R * CW, PPIX = (R + 2) * (CW + 2);
     int status = VQA_ERR_ARG;
@@ -924,7 +986,7 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
         const int KC = 64 / esz;
         const int MTP = (MT + KC - 1) / KC * KC;
         size_t lds = (size_t)(PPIX * pix_stride(CK * esz) + 15) / 16 * 16 + (size_t)MTP * dy_stride(esz, COW) +
-                     (size_t)MTP * 4;                                                // + pixel -> patch table
+                     (size_t)MTP * 4 + (size_t)2 * CK * 4;                         // + pixel -> patch table, XF coeffs
         const int cof = COW >= 32 ? 2 : 1, roles = (CK / 16) * (COW / 16 / cof), nwk = 4 / roles;
         const size_t red = (size_t)(nwk - 1) * roles * 9 * cof * 1024;              // cross-slice combine buffer
         if (lds < red) lds = red;
@@ -936,15 +998,17 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     };
     if (dtype == VQA_BF16) {
         if (MT > 256 || PPIX > 384) return VQA_ERR_ARG;
-#define GO_COW(T, CK, ESZ)                                                       \
-    (COW == 64 ? go(conv3x3_wgrad<T, CK, 64>, CK, ESZ)                           \
-               : (COW == 32 ? go(conv3x3_wgrad<T, CK, 32>, CK, ESZ) : go(conv3x3_wgrad<T, CK, 16>, CK, ESZ)))
+#define GO_XF(T, CK, COW_, ESZ) \
+    (xf ? go(conv3x3_wgrad<T, CK, COW_, true>, CK, ESZ) : go(conv3x3_wgrad<T, CK, COW_, false>, CK, ESZ))
+#define GO_COW(T, CK, ESZ) \
+    (COW == 64 ? GO_XF(T, CK, 64, ESZ) : (COW == 32 ? GO_XF(T, CK, 32, ESZ) : GO_XF(T, CK, 16, ESZ)))
         if (Cin % 32 == 0) status = GO_COW(bf16, 32, 2);
         else if (Cin == 16) status = GO_COW(bf16, 16, 2);
     } else if (dtype == VQA_F32) {
         if (MT > 128 || PPIX > 320) return VQA_ERR_ARG;
         if (Cin % 16 == 0) status = GO_COW(float, 16, 4);
 #undef GO_COW
+#undef GO_XF
     }
     if (status != VQA_OK) return status;
     const int n = Cout * 9 * Cin;

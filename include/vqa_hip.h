@@ -47,12 +47,18 @@ int vqa_conv_pack_all(void* stream, int dtype, int n, const void* const* w, void
  * in_scale / in_shift ([Cin] f32, both or neither; pad must be 0): x is the RAW output of the previous conv and the
  * input is relu(in_scale * x + in_shift) - that layer's nn.BatchNorm2d + nn.ReLU (cnn.py:23-24, ...), applied while
  * the input tile is staged, so the normalised activation is never written (bit-identical to vqa_bn_act_pool_fwd
- * with pool = 0 followed by this call without them). */
+ * with pool = 0 followed by this call without them).
+ * bn_y / bn_coef (both or neither; data-gradient calls: bias NULL, relu 0, stats required): the output y = d is the
+ * gradient w.r.t. the BatchNorm + ReLU output of the layer below (no pool in between), bn_y that layer's raw conv
+ * output (same shape as y), bn_coef its [4][Cout] f32 scale, shift, mean, invstd; `stats` then receives that layer's
+ * BatchNorm-backward partial sums (G rows of [Cout][2]: sum dz, sum dz*xhat, dz = d * 1[scale*bn_y + shift > 0]) -
+ * what vqa_bn_bwd(apply = 0, pool = 0) would produce from (bn_y, d) in a pass of its own; feed vqa_bn_bwd_finalize. */
 int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked, void* y, const float* bias,
                     float* stats, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW,
                     int G, int relu /* 1: y = max(conv + bias, 0) - eval mode with the BatchNorm folded into w, bias */,
-                    const float* in_scale, const float* in_shift);
-int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW);
+                    const float* in_scale, const float* in_shift, const void* bn_y, const float* bn_coef);
+int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW,
+                     int variant /* 0 plain, 1 with in_scale / in_shift, 2 with bn_y / bn_coef */);
 
 /* First encoder layer, bf16 path: nn.Conv2d(3, 16, 3, padding=pad) (cnn.py:23) straight from the NCHW image
  * (in_dtype f16 / f32 / bf16; dataset.py:96-98 stores f16) - no NHWC copy, no channel padding.
@@ -152,6 +158,19 @@ int vqa_gru_gate_fwd(void* stream, int dtype, const float* gi, const float* gh, 
                      float* hnew, void* hnew_t, float* save);
 int vqa_gru_gate_bwd(void* stream, int dtype, const float* dh, const float* save, const float* hprev, int B, int H,
                      void* dgi, void* dgh, float* dhprev);
+
+/* The recurrence of nn.GRU (gru.py:104) in its per-step form, all T steps issued by one call (the step is host-bound:
+ * one binding call instead of 2 T): step t = vqa_gemm(h_t[t] x W_hh^T + b_hh -> gh) then vqa_gru_gate_fwd.  gi
+ * [T][B][3H] f32 (input projections, b_ih included), w_hh T [3H][ldw], h_f f32 / h_t T [T+1][B][H] with slot 0 = h_-1
+ * = 0 filled by the caller, save [T][B][4H], gh [B][3H] f32 scratch, splitk_ws [splits][B][3H] f32 (NULL if splits 1). */
+int vqa_gru_fwd_steps(void* stream, int dtype, const float* gi, const void* w_hh, int ldw, const float* b_hh,
+                      float* h_f, void* h_t, float* save, float* gh, float* splitk_ws, int splits, int B, int T, int H);
+/* BPTT of the same: step t = vqa_gru_gate_bwd then dh_{t-1} += dgh_t x W_hh (vqa_gemm, accumulate).  w_hh_t T
+ * [H][ldw] (W_hh^T, 3H contiguous), outputs dgi / dgh T [T][B][3H], dh_ws [2][B][H] f32 scratch, splitk_ws
+ * [splits][B][H] f32. */
+int vqa_gru_bwd_steps(void* stream, int dtype, const float* dh_last, const float* save, const float* h_f,
+                      const void* w_hh_t, int ldw, void* dgi, void* dgh, float* dh_ws, float* splitk_ws, int splits,
+                      int B, int T, int H);
 
 /* The whole nn.GRU recurrence (gru.py:104) in ONE persistent launch: each workgroup keeps its 48 x H slice of W_hh
  * (bf16) in LDS for all T steps, gates fused in registers, one device-wide barrier per step.  The grid is sized to be

@@ -197,7 +197,7 @@ def test_conv_block_fwd_bwd(prec, tol, cin, cout, S, pad, pool):
     dev = lambda t: t.cuda()
     rm, rv = torch.zeros(cout, device='cuda'), torch.ones(cout, device='cuda')
     a, saved = M.block_fwd(_nhwc(x, dt), dev(w), dev(b), dev(gamma), dev(beta), rm, rv, pad, pool, True)
-    dx, dw, db, dg, dbt = M.block_bwd(_nhwc(da, dt), saved, dev(w), cin, pad, pool, True)
+    dx, dw, db, dg, dbt, _ = M.block_bwd(_nhwc(da, dt), saved, dev(w), cin, pad, pool, True)
     rel = lambda u, v: float((u.double().cpu() - v.double()).norm() / v.double().norm())
     assert rel(a.float().permute(0, 3, 1, 2), a_ref.detach()) < tol
     assert rel(dg, gr.grad) < tol and rel(dbt, br.grad) < tol
@@ -315,3 +315,74 @@ def test_encoder_with_fused_bn_forward_is_bit_identical(prec, padding, pooling, 
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
     for k in outs[0][2]:
         assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('B,c_lo,c_hi,H,W', [(2, 16, 16, 40, 40), (3, 32, 32, 23, 31), (2, 64, 64, 30, 30),
+                                             (2, 128, 128, 16, 14), (3, 256, 256, 12, 12), (1, 16, 16, 226, 226),
+                                             (2, 16, 32, 9, 20)])
+def test_dgrad_with_fused_bn_backward_reduction(prec, B, c_lo, c_hi, H, W):
+    """vqa_conv3x3_fwd as a data gradient with bn_y / bn_coef: the output d is bit-identical to the plain call, and the
+    rows it returns, finalized, equal the BatchNorm-backward sums of the separate reduce pass over (y, d)
+    (vqa_bn_bwd apply = 0, pool = 0) up to fp32 summation order - and the fp64 formula."""
+    import ctypes
+    from vqa_amd import _lib as L, cnn as C
+    torch.manual_seed(c_lo * 3 + c_hi + H)
+    dt = DT[prec]
+    # upper conv: c_lo -> c_hi channels, pad 0, input [B,H,W,c_lo] (the lower block's activation), output H-2 x W-2
+    w = torch.randn(c_hi, c_lo, 3, 3) / (3 * c_lo ** 0.5)
+    dy = torch.randn(B, H - 2, W - 2, c_hi).to(dt).cuda()
+    y_lo = (torch.randn(B, H, W, c_lo) * 1.5).to(dt).cuda()                  # lower layer's raw conv output
+    coef = torch.stack([torch.rand(c_lo) + 0.5, torch.randn(c_lo) * 0.4, torch.randn(c_lo) * 0.3,
+                        torch.rand(c_lo) + 0.7]).cuda()                       # scale, shift, mean, invstd
+    wd = C.pack_weights(w.cuda(), c_lo, dt, dgrad=True)
+    d_plain, _ = C.conv_fwd(dy, wd, None, c_lo, 2, False, kind='dgrad')
+    d_fused, rows = C.conv_fwd(dy, wd, None, c_lo, 2, False, kind='dgrad', bst=(y_lo, coef))
+    assert torch.equal(d_fused, d_plain)
+    n = float(B * H * W)
+    f = lambda: torch.empty(c_lo, device='cuda')
+    out = []
+    nrows = L.lib().vqa_bn_bwd_rows(L.dt(y_lo), B, H, W, c_lo, 0)
+    part = torch.empty(nrows, c_lo, 2, device='cuda')
+    L.call('vqa_bn_bwd', L.dt(y_lo), 0, y_lo, d_plain, None, coef[0], coef[1], coef[2], coef[3], None, None, part,
+           B, H, W, c_lo, 0)
+    for p in (rows, part):
+        dgamma, dbeta, c1, c2 = f(), f(), f(), f()
+        L.check(L.lib().vqa_bn_bwd_finalize(L.stream(), L.ptr(p), p.shape[0], c_lo, ctypes.c_double(n), L.ptr(dgamma),
+                                            L.ptr(dbeta), L.ptr(c1), L.ptr(c2)), 'bn_bwd_finalize')
+        out.append((dgamma.cpu().double(), dbeta.cpu().double()))
+    yl, dd, cf = y_lo.double().cpu(), d_plain.double().cpu(), coef.double().cpu()
+    dz = torch.where(yl * cf[0] + cf[1] > 0, dd, torch.zeros_like(dd))
+    want = ((dz * (yl - cf[2]) * cf[3]).sum((0, 1, 2)), dz.sum((0, 1, 2)))
+    scale = [float(t.abs().max()) for t in want]
+    for got in out:
+        for k in range(2):
+            assert float((got[k] - want[k]).abs().max()) < 2e-5 * max(scale[k], 1.0) * (n ** 0.5)
+    for k in range(2):
+        assert float((out[0][k] - out[1][k]).abs().max()) < 1e-5 * max(scale[k], 1.0) * (n ** 0.5)
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_encoder_with_fused_bn_backward_matches_separate_pass(prec, monkeypatch):
+    """Whole encoder, cnn.FUSE_BN_BWD on (default) vs off: forward identical; gradients equal up to the fp32 summation
+    order of the BatchNorm-backward sums (1e-5 relative per tensor: the sums feed every gradient below them)."""
+    from vqa_amd import cnn as M, synth
+    sd = {k[4:]: v for k, v in synth.state_dict(42, 64, 50, 30).items() if k.startswith('cnn.')}
+    img = synth.images(9, 3, 224).cuda()
+    outs = []
+    for fuse in (32, 0):
+        monkeypatch.setattr(M, 'FUSE_BN_BWD', fuse)
+        m = M.CNN(2, 'max', precision=prec)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        out = m(img)
+        torch.manual_seed(1)
+        (out * torch.rand_like(out)).sum().backward()
+        outs.append((out.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        a, b = outs[0][1][k].double(), outs[1][1][k].double()
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0
+        else:
+            assert float((a - b).norm() / b.norm()) < (1e-5 if prec == 'fp32' else 1e-2), k   # (bf16: dy re-rounded)

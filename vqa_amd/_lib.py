@@ -115,8 +115,11 @@ _call_raw = call
 
 
 def call(name, *args, tag=None):  # noqa: F811
+    """tag: a callable returning the launch's algorithmic work (kind, shape, flops, bytes) - only evaluated while
+    profiling: the step issues ~150 launches and is host-bound, so nothing is formatted on the normal path."""
     if _PROFILE is None:
         return _call_raw(name, *args)
+    tag = tag() if callable(tag) else tag
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _call_raw(name, *args)

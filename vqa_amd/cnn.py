@@ -101,22 +101,28 @@ def _conv_tag(kind, B, OH, OW, cin_real, cout_real, x, y_elems_bytes, w_bytes):
                 bytes=float(x.numel() * x.element_size() + y_elems_bytes + w_bytes))
 
 
-def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', relu=False, in_coeffs=None):
+def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', relu=False, in_coeffs=None, bst=None):
     """x NHWC [B,IH,IW,Cin] -> y [B,OH,OW,Cout] (+ partial BN statistics rows).
     in_coeffs = (scale, shift): x is the previous conv's RAW output and the kernel applies that layer's BatchNorm +
-    ReLU while it stages its input tile (pad must be 0)."""
+    ReLU while it stages its input tile (pad must be 0).
+    bst = (y_below, coef [4,cout]): a data-gradient call whose output is the gradient w.r.t. the BatchNorm + ReLU output
+    of the layer below; the returned rows are that layer's BatchNorm-backward partial sums (for vqa_bn_bwd_finalize)."""
     B, IH, IW, cin = x.shape
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
     R, CW = pick_tile(OH, OW)
     y = torch.empty(B, OH, OW, cout, device=x.device, dtype=x.dtype)
-    G = _plan(L.dt(x), B, IH, IW, cin, OH, OW, cout, pad, R, CW)
-    stats = torch.empty(G, cout, 2, device=x.device, dtype=torch.float32) if want_stats else None
+    G = _plan(L.dt(x), B, IH, IW, cin, OH, OW, cout, pad, R, CW, 1 if in_coeffs is not None else (2 if bst else 0))
+    stats = torch.empty(G, cout, 2, device=x.device, dtype=torch.float32) if (want_stats or bst) else None
     cr = cin if cin_real is None else cin_real
-    tag = _conv_tag(kind, B, OH, OW, cr, cout, x,
-                    y.numel() * y.element_size(), wpk.numel() * wpk.element_size())
+    # (algorithmic bytes of the launch: + the lower layer's y when its BatchNorm-backward sums are formed here)
+    tag = lambda: _conv_tag(kind, B, OH, OW, cr, cout, x, y.numel() * y.element_size() * (2 if bst else 1),
+                            wpk.numel() * wpk.element_size())
     isc, ish = in_coeffs if in_coeffs is not None else (None, None)
+    by, bcoef = bst if bst else (None, None)
+    if bst:
+        assert by.shape == y.shape and by.dtype == y.dtype and by.is_contiguous() and tuple(bcoef.shape) == (4, cout)
     L.call('vqa_conv3x3_fwd', L.dt(x), x, wpk, y, bias, stats, B, IH, IW, cin, OH, OW, cout, pad, R, CW, G, int(relu),
-           isc, ish, tag=tag)
+           isc, ish, by, bcoef, tag=tag)
     return y, stats
 
 
@@ -153,7 +159,7 @@ def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None):
     G = max(1, min(tiles, (256 * per_cu) // pairs if pairs <= 256 * per_cu else 1))
     part = torch.empty(G, cout, 9, cin, device=x.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)
-    tag = _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4)
+    tag = lambda: _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4)
     isc, ish = in_coeffs if in_coeffs is not None else (None, None)
     L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw, G, B, IH, IW, cin, cin_real, OH, OW, cout, pad, R, CW,
            isc, ish, tag=tag)
@@ -163,7 +169,7 @@ def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None):
 def bn_act_pool(y, scale, shift, pool):
     B, H, W, C = y.shape
     a = torch.empty(B, H // 2 if pool else H, W // 2 if pool else W, C, device=y.device, dtype=y.dtype)
-    tag = dict(kind='fwd', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((y.numel() + a.numel()) * y.element_size()))
+    tag = lambda: dict(kind='fwd', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((y.numel() + a.numel()) * y.element_size()))
     L.call('vqa_bn_act_pool_fwd', L.dt(y), y, a, scale, shift, B, H, W, C, pool, tag=tag)
     return a
 
@@ -208,7 +214,7 @@ def first_fwd(images, w, bias, pad, want_stats, wscale=None, relu=False, mirror=
     y = torch.empty(B, OH, OW, 16, device=images.device, dtype=torch.bfloat16)
     G = min(B * (-(-OH // R)) * (-(-OW // CW)), 256 * 5)      # persistent workgroups: 5 resident per CU (92 VGPRs)
     stats = torch.empty(G, 16, 2, device=images.device, dtype=torch.float32) if want_stats else None
-    tag = dict(kind='first', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
+    tag = lambda: dict(kind='first', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
                bytes=float(images.numel() * images.element_size() + y.numel() * 2 + w.numel() * 4))
     L.call('vqa_conv3x3_first_fwd', L.dt(images), images, w, y, bias, stats, B, IH, IW, OH, OW, pad, R, CW, G,
            wscale, int(relu), int(mirror), tag=tag)
@@ -226,10 +232,11 @@ def first_wgrad(images, dy, pad, out=None, mirror=False, bn=None):
     G = min(tiles, 256 * (4 if bn is not None else 5))
     part = torch.empty(G, 16, 32, device=dy.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty(16, 3, 3, 3, device=dy.device, dtype=torch.float32)
-    tag = dict(kind='first_wgrad', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
+    tag = lambda: dict(kind='first_wgrad', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
                bytes=float(images.numel() * images.element_size() + dy.numel() * 2))
     if bn is not None:
-        tag['bytes'] += dy.numel() * 2
+        tag0 = tag
+        tag = lambda: dict(tag0(), bytes=tag0()['bytes'] + dy.numel() * 2)
         L.call('vqa_conv3x3_first_wgrad_bn', L.dt(images), images, dy, *bn, part, dw, G, B, IH, IW, OH, OW, pad, R, CW,
                int(mirror), tag=tag)
         return dw
@@ -251,7 +258,7 @@ def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False,
         if wpk is None:
             wpk = pack_weights(w, x.shape[3], x.dtype, dgrad=False)
         y, stats = conv_fwd(x, wpk, bias, cout, pad, training, cin_real=w.shape[1], in_coeffs=in_coeffs)
-    scale, shift, mean, invstd = torch.empty(4, cout, device=dev, dtype=torch.float32).unbind(0)
+    scale, shift, mean, invstd = torch.empty(4, cout, device=dev, dtype=torch.float32).unbind(0)   # ONE [4,C] block
     if training:
         count = float(y.shape[0] * y.shape[1] * y.shape[2])
         L.check(L.lib().vqa_bn_finalize(L.stream(), L.ptr(stats), stats.shape[0], cout, L.ctypes.c_double(count),
@@ -265,16 +272,28 @@ def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False,
     return a, (x, y, scale, shift, mean, invstd)
 
 
+def coef_block(scale, shift, mean, invstd):
+    """The [4,C] tensor (scale, shift, mean, invstd) that block_fwd made the four vectors views of."""
+    C = scale.numel()
+    assert (shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()) == tuple(scale.data_ptr() + 4 * C * k for k in (1, 2, 3))
+    return scale.as_strided((4, C), (C, 1))
+
+
 def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None, params=None, mirror=False,
-              side=None, in_coeffs=None):
-    """d = gradient w.r.t. the block output (NHWC, activation dtype).  Returns (dx, dw, dbias, dgamma, dbeta).
-    side: HIP stream for the weight gradient (off the dgrad -> BatchNorm-backward chain), None = current stream."""
+              side=None, in_coeffs=None, part=None, bst=None):
+    """d = gradient w.r.t. the block output (NHWC, activation dtype).  Returns (dx, dw, dbias, dgamma, dbeta, below).
+    side: HIP stream for the weight gradient (off the dgrad -> BatchNorm-backward chain), None = current stream.
+    part: this block's BatchNorm-backward partial sums, already produced by the data gradient of the block above.
+    bst = (y, coef) of the block BELOW: this block's data gradient also produces that block's partial sums (`below`)."""
     x, y, scale, shift, mean, invstd = saved
     dev = y.device
     B, H, W, C = y.shape
     count = float(B * H * W)
-    rows = L.lib().vqa_bn_bwd_rows(L.dt(y), B, H, W, C, pool)
-    part = torch.empty(rows, C, 2, device=dev, dtype=torch.float32)
+    have_part = part is not None
+    if not have_part:
+        rows = L.lib().vqa_bn_bwd_rows(L.dt(y), B, H, W, C, pool)
+        part = torch.empty(rows, C, 2, device=dev, dtype=torch.float32)
+    rows = part.shape[0]
     # gradients go straight into the flat gradient buffer when the parameters live in one (ops.grad_dst)
     _, pb, pg, pbt = params if params is not None else (None, None, None, None)
     dw_out = ops.grad_dst(w)
@@ -285,9 +304,10 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
         dbeta = torch.empty(C, device=dev, dtype=torch.float32)
     c1, c2 = torch.empty(2, C, device=dev, dtype=torch.float32).unbind(0)
     es = y.element_size()
-    tag = dict(kind='reduce', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((y.numel() + d.numel()) * es))
-    L.call('vqa_bn_bwd', L.dt(y), 0, y, d, None, scale, shift, mean, invstd, None, None, part, B, H, W, C, pool,
-           tag=tag)
+    if not have_part:
+        tag = lambda: dict(kind='reduce', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((y.numel() + d.numel()) * es))
+        L.call('vqa_bn_bwd', L.dt(y), 0, y, d, None, scale, shift, mean, invstd, None, None, part, B, H, W, C, pool,
+               tag=tag)
     L.check(L.lib().vqa_bn_bwd_finalize(L.stream(), L.ptr(part), rows, C, L.ctypes.c_double(count), L.ptr(dgamma),
                                         L.ptr(dbeta), L.ptr(c1), L.ptr(c2)), 'vqa_bn_bwd_finalize')
     if first and pool == 0 and not need_dx and FUSE_FIRST_BN:
@@ -303,9 +323,9 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
                 t.record_stream(side)
         if dbias is None:
             dbias = torch.zeros(C, device=dev, dtype=torch.float32)
-        return None, dw, dbias, dgamma, dbeta
+        return None, dw, dbias, dgamma, dbeta, None
     dy = torch.empty_like(y)
-    tag = dict(kind='apply', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((2 * y.numel() + d.numel()) * es))
+    tag = lambda: dict(kind='apply', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((2 * y.numel() + d.numel()) * es))
     L.call('vqa_bn_bwd', L.dt(y), 1, y, d, dy, scale, shift, mean, invstd, c1, c2, None, B, H, W, C, pool, tag=tag)
     def wgrad():
         return (first_wgrad(x, dy, pad, out=dw_out, mirror=mirror) if first
@@ -313,13 +333,13 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
 
     def dgrad():
         if not need_dx:
-            return None
+            return None, None
         wd = wpk_d if wpk_d is not None else pack_weights(w, x.shape[3], x.dtype, dgrad=True)
-        return conv_fwd(dy, wd, None, x.shape[3], 2 - pad, False, kind='dgrad')[0]
+        return conv_fwd(dy, wd, None, x.shape[3], 2 - pad, False, kind='dgrad', bst=bst)
 
     if side is None:
         dw = wgrad()
-        dx = dgrad()
+        dx, below = dgrad()
     else:
         # (enqueueing the data gradient first instead measured the same)
         side.wait_event(torch.cuda.current_stream().record_event())
@@ -327,13 +347,13 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
             dw = wgrad()
         dy.record_stream(side)
         x.record_stream(side)
-        dx = dgrad()
+        dx, below = dgrad()
     # the conv bias feeds a training-mode BatchNorm: its gradient is identically zero (the reference produces
     # rounding noise ~1e-7 of the weight-gradient scale here)
     # (its slot in the flat gradient buffer is never written: zero from FlatParams' initial fill)
     if dbias is None:
         dbias = torch.zeros(C, device=dev, dtype=torch.float32)
-    return dx, dw, dbias, dgamma, dbeta
+    return dx, dw, dbias, dgamma, dbeta, below
 
 
 _POOL_ID = {}
@@ -385,6 +405,12 @@ WGRAD_STREAM = os.environ.get('VQA_WGRAD_STREAM', '1') != '0'
 # normalised activation is never written (5 passes and 1.6 GB of traffic per step at B = 256).  VQA_FUSE_BN_FWD=0: the
 # separate pass (bit-identical results).
 FUSE_BN_FWD = os.environ.get('VQA_FUSE_BN_FWD', '1') != '0'
+# Backward: the data gradient of a block's second conv produces the gradient d w.r.t. the first conv's BatchNorm + ReLU
+# output; with the first conv's raw output y prefetched beside it, its epilogue also accumulates that BatchNorm's
+# backward sums (sum dz, sum dz*xhat) - the reduce pass over (y, d) never runs.  VQA_FUSE_BN_BWD=0: the separate pass.
+# Only where that data gradient is the single-chunk persistent kernel (16 / 32 channels: HBM-bound, one |y| of
+# traffic less); in the multi-chunk kernel the extra reads cost more than the pass (58x58x64: +0.10 ms for 0.046).
+FUSE_BN_BWD = int(os.environ.get('VQA_FUSE_BN_BWD', '32'))      # largest channel count it is applied to; 0 = never
 FUSE_FIRST_BN = os.environ.get('VQA_FUSE_FIRST_BN', '1') != '0'
 _WGRAD_STREAMS = {}
 
@@ -447,15 +473,21 @@ class _CnnFunction(torch.autograd.Function):
         pool_last = ctx.meta[9][1]
         d = dout.reshape(B, H // 2 if pool_last else H, W // 2 if pool_last else W, C).to(dtype).contiguous()
         side = _wgrad_stream(dout.device) if WGRAD_STREAM else None
+        part = None
         for li in range(9, -1, -1):
             pad, pool, fused_in = ctx.meta[li]
+            # the block below has no pool: this block's data gradient can also do its BatchNorm-backward reduction
+            bst = None
+            if li > 0 and ctx.meta[li - 1][1] == 0 and CHANNELS[li] <= min(FUSE_BN_BWD, _ck(CHANNELS[li], dtype)):
+                bst = (saved[6 * (li - 1) + 1], coef_block(*saved[6 * (li - 1) + 2: 6 * (li - 1) + 6]))
             # fused_in: this layer's input x is the previous layer's raw conv output; its weight gradient re-applies
             # that layer's BatchNorm + ReLU (saved scale / shift) as the forward conv did
             in_coeffs = (saved[6 * (li - 1) + 2], saved[6 * (li - 1) + 3]) if fused_in else None
-            d, dw, db, dg, dbt = block_bwd(d, saved[6 * li: 6 * li + 6], params[4 * li], CHANNELS[li], pad, pool,
-                                           li > 0, first=ctx.first and li == 0, wpk_d=ctx.wd[li],
-                                           mirror=ctx.mirror and li == 0,
-                                           params=params[4 * li: 4 * li + 4], side=side, in_coeffs=in_coeffs)
+            d, dw, db, dg, dbt, part = block_bwd(d, saved[6 * li: 6 * li + 6], params[4 * li], CHANNELS[li], pad, pool,
+                                                 li > 0, first=ctx.first and li == 0, wpk_d=ctx.wd[li],
+                                                 mirror=ctx.mirror and li == 0,
+                                                 params=params[4 * li: 4 * li + 4], side=side, in_coeffs=in_coeffs,
+                                                 part=part, bst=bst)
             grads[4 * li: 4 * li + 4] = [dw, db, dg, dbt]
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)

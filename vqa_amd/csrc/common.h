@@ -111,6 +111,8 @@ __device__ __forceinline__ void load4(const float* p, float* v) {
 //   out   = round_T(acc + bias), optionally max(., 0)
 //   s1/s2 += okf * out, (okf * out)^2       (okf = 1 for a pixel inside the image, 0 otherwise)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <typename T> struct Packed4;
 template <> struct Packed4<bf16> { unsigned lo, hi; };        // channels 0-1, 2-3 as bf16 pairs
 template <> struct Packed4<float> { f32x2 lo, hi; };
@@ -142,6 +144,56 @@ __device__ __forceinline__ Packed4<T> epilogue4(const f32x4& acc, const f32x4& b
     }
     return out;
 }
+// The same epilogue for a DATA-GRADIENT conv whose output d is the gradient w.r.t. the BatchNorm + ReLU output of the
+// layer below (no pool in between): instead of the forward statistics it accumulates that layer's BatchNorm-backward
+// sums (bn.hip: bn_bwd<APPLY = false, pool = 0>) from the stored d and the layer's raw conv output y at the same
+// (pixel, channels):  dz = d * 1[scale*y + shift > 0],  s1 += dz,  s2 += dz * (y - mean) * invstd.
+// y4 = this lane's 4 channels of y (as loaded: 8 bytes of bf16 / 16 bytes of f32), cf = {scale, shift, mean, invstd}.
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16> { unsigned lo, hi; };
+template <> struct Raw4<float> { f32x2 lo, hi; };
+template <typename T>
+__device__ __forceinline__ Packed4<T> epilogue4_bnbwd(const f32x4& acc, float okf, const Raw4<T>& y4,
+                                                      const f32x4 (&cf)[4], f32x2 (&s1)[2], f32x2 (&s2)[2]) {
+    const f32x2 p[2] = {f32x2{acc[0], acc[1]}, f32x2{acc[2], acc[3]}};
+    Packed4<T> out;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x2 v, yv;
+        if constexpr (sizeof(T) == 2) {
+            typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bf16x2_t t = {(bf16)p[h].x, (bf16)p[h].y};
+            const unsigned bits = __builtin_bit_cast(unsigned, t);
+            (h ? out.hi : out.lo) = bits;
+            v = f32x2{__uint_as_float(bits << 16), __uint_as_float(bits & 0xFFFF0000u)};            // what is stored
+            const unsigned yb = h ? y4.hi : y4.lo;
+            yv = f32x2{__uint_as_float(yb << 16), __uint_as_float(yb & 0xFFFF0000u)};
+        } else {
+            (h ? out.hi : out.lo) = p[h];
+            v = p[h];
+            yv = h ? y4.hi : y4.lo;
+        }
+        const f32x2 sc = {cf[0][2 * h], cf[0][2 * h + 1]}, sh = {cf[1][2 * h], cf[1][2 * h + 1]},
+                    mu = {cf[2][2 * h], cf[2][2 * h + 1]}, is = {cf[3][2 * h], cf[3][2 * h + 1]};
+        const f32x2 z = __builtin_elementwise_fma(yv, sc, sh);
+        f32x2 dz = v * f32x2{okf, okf};
+        dz.x = z.x > 0.f ? dz.x : 0.f;
+        dz.y = z.y > 0.f ? dz.y : 0.f;
+        const f32x2 xh = (yv - mu) * is;
+        s1[h] += dz;
+        s2[h] = __builtin_elementwise_fma(dz, xh, s2[h]);
+    }
+    return out;
+}
+template <typename T> __device__ __forceinline__ Raw4<T> buffer_load_raw4(__amdgpu_buffer_rsrc_t r, unsigned off);
+template <> __device__ __forceinline__ Raw4<bf16> buffer_load_raw4<bf16>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    return Raw4<bf16>{v.x, v.y};
+}
+template <> __device__ __forceinline__ Raw4<float> buffer_load_raw4<float>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return Raw4<float>{f32x2{__uint_as_float(v.x), __uint_as_float(v.y)}, f32x2{__uint_as_float(v.z), __uint_as_float(v.w)}};
+}
 template <typename T> __device__ __forceinline__ void store_packed4(T* p, const Packed4<T>& o);
 template <> __device__ __forceinline__ void store_packed4<bf16>(bf16* p, const Packed4<bf16>& o) {
     *reinterpret_cast<uint2*>(p) = make_uint2(o.lo, o.hi);
@@ -154,8 +206,6 @@ template <> __device__ __forceinline__ void store_packed4<float>(float* p, const
 // the tile overhang: an out-of-image element gets the offset `size` (one select) instead of a clamped address, an AND
 // mask over the loaded data at the LDS write and a branch around the store - and straight-line code is also what lets
 // the compiler count its s_waitcnt vmcnt exactly (behind a branch that may skip the stores it waits for them too).
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }

@@ -38,6 +38,12 @@ struct ConvArgs {
     // pad == 0 (every conv that follows an un-pooled block, cnn.py:24,28,32,36,40): no zero padding to preserve.
     const float* in_scale;
     const float* in_shift;
+    // BST kernels (data gradient): y = d is the gradient w.r.t. the BatchNorm + ReLU output of the layer below (no pool
+    // in between), bn_y that layer's raw conv output (same shape as y) and bn_coef its [4][Cout] scale, shift, mean,
+    // invstd: `stats` then receives that layer's BatchNorm-BACKWARD partial sums (sum dz, sum dz*xhat) instead of the
+    // forward statistics - its reduce pass (bn.hip) never runs, d is not re-read.
+    const void* bn_y;
+    const float* bn_coef;
 };
 
 template <typename T, int CK> struct ConvCfg {
@@ -65,8 +71,9 @@ __device__ unsigned long long g_stamps[16384][12];
 // ---------------------------------------------------------------------------------------------- igemm
 // One workgroup per (tile, image, channel block): the multi-chunk (Cin > CK) layers, which are MFMA-bound and
 // want their registers for the accumulators and the chunk prefetch rather than for persistent-loop state.
-template <typename T, int CK, int NBF, bool XF>
+template <typename T, int CK, int NBF, int VAR>   // VAR: 0 plain, 1 XF (input BatchNorm + ReLU), 2 BST (see ConvArgs)
 __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
+    constexpr bool XF = VAR == 1, BST = VAR == 2;
     using Cfg = ConvCfg<T, CK>;
     constexpr int VEC = Cfg::VEC, KC = Cfg::KC, KP = Cfg::KP, NS = Cfg::NS, PXB = Cfg::PXB, WROWB = Cfg::WROWB,
                   VPP = Cfg::VPP;
@@ -85,6 +92,9 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
             coefl[i] = a.in_scale[i];
             coefl[a.Cin + i] = a.in_shift[i];
         }
+    }
+    if constexpr (BST) {                                        // [4][NB] of this channel block (read in the epilogue)
+        for (int i = tid; i < 4 * NB; i += 256) coefl[i] = a.bn_coef[(i / NB) * a.Cout + blockIdx.z * NB + i % NB];
     }
 
     const int tile = blockIdx.x, b = blockIdx.y, co0 = blockIdx.z * NB;
@@ -120,7 +130,20 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
 #pragma unroll
     for (int n = 0; n < NBF; ++n)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[n][e] = a.bias ? a.bias[co0 + n * 16 + q * 4 + e] : 0.f;
+        for (int e = 0; e < 4; ++e) bv[n][e] = (!BST && a.bias) ? a.bias[co0 + n * 16 + q * 4 + e] : 0.f;
+    // BST: this lane's 4 channels of the lower layer's y at each of its output pixels, loaded up front (a whole
+    // chunk loop of lead time; out-of-tile pixels read zeros beyond the buffer)
+    Raw4<T> yv[BST ? 4 : 1][BST ? NBF : 1];
+    if constexpr (BST) {
+        const unsigned ybytes = (unsigned)a.B * a.OH * a.OW * a.Cout * (unsigned)sizeof(T);
+        const __amdgpu_buffer_rsrc_t bybuf = buffer_of(a.bn_y, ybytes);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int n = 0; n < NBF; ++n)
+                yv[f][n] = buffer_load_raw4<T>(bybuf, opix[f] >= 0 ? (unsigned)(opix[f] * a.Cout + co0 + n * 16 + q * 4) *
+                                                                       (unsigned)sizeof(T) : ybytes);
+    }
     // ---- staging plan.  Every thread moves up to NPV patch vectors and NWV weight vectors per channel chunk.  The
     // loads are branch-free (out-of-image / out-of-range lanes read a valid dummy address and are zeroed by a
     // select) so that all of a chunk's loads are in flight together, and the loads of chunk ch+1 are issued before
@@ -258,11 +281,32 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
             }
         }
     };
-    switch ((a.relu ? 1 : 0) | (a.stats ? 2 : 0)) {
-        case 0: finish(std::integral_constant<int, 0>{}); break;
-        case 1: finish(std::integral_constant<int, 1>{}); break;
-        case 2: finish(std::integral_constant<int, 2>{}); break;
-        default: finish(std::integral_constant<int, 3>{}); break;
+    if constexpr (BST) {
+        // the coefficients sit beyond the transpose regions' reach?  No: ew / epix / red overlay the staging LDS from
+        // offset 0 and coefl lies behind patch + weights - copy this lane's coefficients to registers first
+        f32x4 cf[NBF][4];
+#pragma unroll
+        for (int n = 0; n < NBF; ++n)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cf[n][k] = *reinterpret_cast<const f32x4*>(coefl + k * NB + n * 16 + q * 4);
+        __syncthreads();                                    // every wave has its coefficients before LDS is reused
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float okf = opix[f] >= 0 ? 1.f : 0.f;
+            if (q == 0) epix[f * 16 + r] = opix[f];
+#pragma unroll
+            for (int n = 0; n < NBF; ++n) {
+                const Packed4<T> o = epilogue4_bnbwd<T>(acc[f][n], okf, yv[f][n], cf[n], s1[n], s2[n]);
+                store_packed4<T>(reinterpret_cast<T*>(ew + (f * 16 + r) * EROW) + n * 16 + q * 4, o);
+            }
+        }
+    } else {
+        switch ((a.relu ? 1 : 0) | (a.stats ? 2 : 0)) {
+            case 0: finish(std::integral_constant<int, 0>{}); break;
+            case 1: finish(std::integral_constant<int, 1>{}); break;
+            case 2: finish(std::integral_constant<int, 2>{}); break;
+            default: finish(std::integral_constant<int, 3>{}); break;
+        }
     }
     STAMP(7);
     if (a.stats) {
@@ -306,8 +350,14 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
 // tile is computed once per workgroup (fragment pixel decode, patch vector coordinates), the weight slab and the bias
 // stay resident in LDS, the next tile's patch is prefetched into registers during the MFMAs, and the BatchNorm
 // partial sums stay in registers across tiles: ONE statistics row per workgroup.
-template <typename T, int CK, int NBF, bool XF>
-__global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
+// (the BST form of the 32-channel kernel is held to the three waves per SIMD its plain form has: left alone the
+// compiler spends 217 registers on it)
+template <typename T, int CK, int NBF, int VAR>
+#ifndef VQA_BST_WAVES
+#define VQA_BST_WAVES 3
+#endif
+__global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) void conv3x3_igemm_p(ConvArgs a) {
+    constexpr bool XF = VAR == 1, BST = VAR == 2;
     using Cfg = ConvCfg<T, CK>;
     constexpr int VEC = Cfg::VEC, KC = Cfg::KC, KP = Cfg::KP, NS = Cfg::NS, PXB = Cfg::PXB, WROWB = Cfg::WROWB,
                   VPP = Cfg::VPP;
@@ -366,7 +416,11 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
             if (tid < CK) { coefl[tid] = a.in_scale[tid]; coefl[CK + tid] = a.in_shift[tid]; }
             __syncthreads();                                    // read by the first stash
         }
+        if constexpr (BST) {                                    // [4][NB] (read in the epilogue, behind the loop's barrier)
+            for (int i = tid; i < 4 * NB; i += 256) coefl[i] = a.bn_coef[(i / NB) * a.Cout + co0 + i % NB];
+        }
     }
+    const __amdgpu_buffer_rsrc_t bybuf = buffer_of(BST ? a.bn_y : a.y, ybytes);
 
     f32x4 acc[4][NBF];
     f32x2 s1[NBF][2], s2[NBF][2];
@@ -418,6 +472,23 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
         stash();
         __syncthreads();
         const int cb = fb, coy0 = foy0, cox0 = fox0;            // the tile being computed
+        // BST: byte offsets of this lane's output pieces (also those of the lower layer's y), and the y loads - issued
+        // BEFORE the next tile's patch loads so that the epilogue's wait does not include those
+        unsigned yoff[BST ? 4 : 1][BST ? NBF : 1];
+        Raw4<T> yv[BST ? 4 : 1][BST ? NBF : 1];
+        if constexpr (BST) {
+            const unsigned yt0 = ((unsigned)((cb * a.OH + coy0) * a.OW + cox0) * a.Cout + co0 + q * 4) * (unsigned)sizeof(T);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int pr = frc[f] >> 16, pc = frc[f] & 0xFFFF;
+                const bool ok = coy0 + pr < a.OH && cox0 + pc < a.OW;
+#pragma unroll
+                for (int n = 0; n < NBF; ++n) {
+                    yoff[f][n] = ok ? yt0 + (unsigned)((pr * a.OW + pc) * a.Cout + n * 16) * (unsigned)sizeof(T) : ybytes;
+                    yv[f][n] = buffer_load_raw4<T>(bybuf, yoff[f][n]);
+                }
+            }
+        }
         if (t + (int)gridDim.x < total) fetch(t + gridDim.x);
 #pragma unroll
         for (int f = 0; f < 4; ++f)
@@ -459,11 +530,26 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_p(ConvArgs a) {
                 }
             }
         };
-        switch ((a.relu ? 1 : 0) | (a.stats ? 2 : 0)) {
-            case 0: finish(std::integral_constant<int, 0>{}); break;
-            case 1: finish(std::integral_constant<int, 1>{}); break;
-            case 2: finish(std::integral_constant<int, 2>{}); break;
-            default: finish(std::integral_constant<int, 3>{}); break;
+        if constexpr (BST) {
+#pragma unroll
+            for (int n = 0; n < NBF; ++n) {
+                f32x4 cf[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cf[k] = *reinterpret_cast<const f32x4*>(coefl + k * NB + n * 16 + q * 4);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const float okf = yoff[f][n] != ybytes ? 1.f : 0.f;
+                    const Packed4<T> o = epilogue4_bnbwd<T>(acc[f][n], okf, yv[f][n], cf, s1[n], s2[n]);
+                    buffer_store_packed4<T>(ybuf, yoff[f][n], o);
+                }
+            }
+        } else {
+            switch ((a.relu ? 1 : 0) | (a.stats ? 2 : 0)) {
+                case 0: finish(std::integral_constant<int, 0>{}); break;
+                case 1: finish(std::integral_constant<int, 1>{}); break;
+                case 2: finish(std::integral_constant<int, 2>{}); break;
+                default: finish(std::integral_constant<int, 3>{}); break;
+            }
         }
         __syncthreads();
     }
@@ -499,7 +585,7 @@ size_t igemm_lds(const ConvArgs& a) {
                        (size_t)4 * NBF * 16 * 2 * 4;                                   // + their statistics rows
     if (lds < epi) lds = epi;
     lds += (size_t)NBF * 16 * 4;                                                       // resident bias row
-    lds += (size_t)2 * a.Cin * 4;                                                      // XF: input scale / shift
+    lds += (size_t)2 * a.Cin * 4 + (size_t)4 * NBF * 16 * 4;                           // XF / BST coefficient rows
     return lds;
 }
 
@@ -512,9 +598,10 @@ int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
     const int total = a.tiles_x * a.tiles_y * a.B, zb = a.Cout / (NBF * 16);
     if (lds > 160 * 1024) return plan_only ? -1 : VQA_ERR_ARG;
     const bool persistent = a.Cin == CK;
-    const bool xf = a.in_scale != nullptr;
-    auto kp = xf ? conv3x3_igemm_p<T, CK, NBF, true> : conv3x3_igemm_p<T, CK, NBF, false>;
-    auto kt = xf ? conv3x3_igemm_tile<T, CK, NBF, true> : conv3x3_igemm_tile<T, CK, NBF, false>;
+    const int var = a.in_scale ? 1 : (a.bn_y ? 2 : 0);
+    auto kp = var == 1 ? conv3x3_igemm_p<T, CK, NBF, 1> : (var == 2 ? conv3x3_igemm_p<T, CK, NBF, 2> : conv3x3_igemm_p<T, CK, NBF, 0>);
+    auto kt = var == 1 ? conv3x3_igemm_tile<T, CK, NBF, 1>
+                       : (var == 2 ? conv3x3_igemm_tile<T, CK, NBF, 2> : conv3x3_igemm_tile<T, CK, NBF, 0>);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(persistent ? (const void*)kp : (const void*)kt,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -922,9 +1009,11 @@ __global__ void nchw_to_nhwc(const TI* in, T* out, int B, int C, int H, int W, i
 static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* wpacked, void* y, const float* bias,
                           float* stats, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW,
                           int G, bool plan_only, int relu = 0, const float* in_scale = nullptr,
-                          const float* in_shift = nullptr) {
+                          const float* in_shift = nullptr, const void* bn_y = nullptr, const float* bn_coef = nullptr) {
     const int bad = plan_only ? -1 : VQA_ERR_ARG;
     if ((in_scale != nullptr) != (in_shift != nullptr) || (in_scale && pad != 0)) return bad;
+    if ((bn_y != nullptr) != (bn_coef != nullptr) || (bn_y && (in_scale || relu || bias || (!plan_only && !stats))))
+        return bad;
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || R * CW > 256 ||
         (R + 2) * (CW + 2) > 384 || B < 1)
         return bad;
@@ -933,7 +1022,7 @@ static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* w
     if ((double)B * IH * IW * Cin * esz_ >= 4294967040.0 || (double)B * OH * OW * Cout * esz_ >= 4294967040.0) return bad;
     const int tx_ = (OW + CW - 1) / CW, ty_ = (OH + R - 1) / R;
     ConvArgs a{x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
-               1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), relu, in_scale, in_shift};
+               1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), relu, in_scale, in_shift, bn_y, bn_coef};
     if (dtype == VQA_BF16) {
         if (Cin % 32 == 0) return dispatch_nb<bf16, 32>(s, a, G, plan_only);
         if (Cin == 16) return dispatch_nb<bf16, 16>(s, a, G, plan_only);
@@ -946,9 +1035,9 @@ static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* w
 extern "C" int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked, void* y,
                                const float* bias, float* stats, int B, int IH, int IW, int Cin, int OH, int OW,
                                int Cout, int pad, int R, int CW, int G, int relu, const float* in_scale,
-                               const float* in_shift) {
+                               const float* in_shift, const void* bn_y, const float* bn_coef) {
     return conv_fwd_entry(static_cast<hipStream_t>(stream), dtype, x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW,
-                          Cout, pad, R, CW, G, false, relu, in_scale, in_shift);
+                          Cout, pad, R, CW, G, false, relu, in_scale, in_shift, bn_y, bn_coef);
 }
 
 // G for vqa_conv3x3_fwd: persistent workgroups per output-channel block = rows of `stats`; -1 = unsupported shape
@@ -958,9 +1047,14 @@ extern "C" int dbg_conv_stamps(void* out) {     // host buffer of 16384 * 12 u64
 }
 #endif
 extern "C" int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R,
-                                int CW) {
+                                int CW, int variant) {
+    // the variants are different instantiations with their own register counts, hence their own resident grids
+    static const float dummy = 0.f;
+    const float* xf = variant == 1 ? &dummy : nullptr;
+    const float* bst = variant == 2 ? &dummy : nullptr;
+    if (variant < 0 || variant > 2) return -1;
     return conv_fwd_entry(nullptr, dtype, nullptr, nullptr, nullptr, nullptr, nullptr, B, IH, IW, Cin, OH, OW, Cout,
-                          pad, R, CW, 0, true);
+                          pad, R, CW, 0, true, 0, xf, xf, bst, bst);
 }
 
 extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const void* dy, float* part, float* dw,

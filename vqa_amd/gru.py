@@ -78,11 +78,12 @@ class _GruFunction(torch.autograd.Function):
         if not (_persistent_ok(dtype, H) and
                 L.fits('vqa_gru_fwd_persistent', gi, whh, whh.stride(0), b_hh, h_f, h_t, save, B, T, H,
                        torch.empty(2, device=dev, dtype=torch.int32), PERSISTENT_MAX_WG)):
+            # T x (recurrent GEMM + gate kernel), issued by one call (vqa_gru_fwd_steps: same launches, no per-step
+            # trip through the binding)
             gh = torch.empty(B, 3 * H, device=dev, dtype=torch.float32)
-            for t in range(T):
-                ops.gemm(h_t[t], whh, out=gh, bias=b_hh)
-                L.call('vqa_gru_gate_fwd', L.dt(x), gi[t * B:(t + 1) * B], gh, h_f[t], B, H, h_f[t + 1], h_t[t + 1],
-                       save[t])
+            splits = ops.gemm_splits(B, 3 * H, H, dtype)
+            ws = torch.empty(splits, B, 3 * H, device=dev, dtype=torch.float32) if splits > 1 else None
+            L.call('vqa_gru_fwd_steps', L.dt(x), gi, whh, whh.stride(0), b_hh, h_f, h_t, save, gh, ws, splits, B, T, H)
         ctx.save_for_backward(q, x, h_f, h_t, save, w_ih, w_hh, emb, b_ih, b_hh)
         ctx.dtype = dtype
         return h_f[T].clone()
@@ -103,13 +104,11 @@ class _GruFunction(torch.autograd.Function):
         if not (_persistent_ok(dtype, H) and
                 L.fits('vqa_gru_bwd_persistent', whh_T, whh_T.stride(0), h_f, save, dh, dgi, dgh, B, T, H,
                        torch.empty(2, device=dev, dtype=torch.int32), PERSISTENT_MAX_WG)):
-            for t in range(T - 1, -1, -1):
-                dprev = torch.empty(B, H, device=dev, dtype=torch.float32)
-                L.call('vqa_gru_gate_bwd', L.dt(x), dh, save[t], h_f[t], B, H, dgi[t * B:(t + 1) * B],
-                       dgh[t * B:(t + 1) * B], dprev)
-                if t > 0:
-                    ops.gemm(dgh[t * B:(t + 1) * B], whh_T, out=dprev, accumulate=True)   # += dgh_t @ W_hh
-                dh = dprev
+            dh_ws = torch.empty(2, B, H, device=dev, dtype=torch.float32)
+            splits = ops.gemm_splits(B, H, 3 * H, dtype)
+            ws = torch.empty(splits, B, H, device=dev, dtype=torch.float32) if splits > 1 else None
+            L.call('vqa_gru_bwd_steps', L.dt(x), dh, save, h_f, whh_T, whh_T.stride(0), dgi, dgh, dh_ws, ws, splits,
+                   B, T, H)
         hprev = h_t[:T].reshape(T * B, H)
         # parameter gradients are written into the flat gradient buffer when there is one (ops.grad_dst)
         dw_hh = ops.gemm(dgh, hprev, trans=True, out=ops.grad_dst(w_hh))          # [3H, H]

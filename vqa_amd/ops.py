@@ -28,22 +28,25 @@ def gemm(A, B, trans=False, M=None, N=None, K=None, out=None, out_dtype=torch.fl
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=out_dtype)
     assert out.stride(1) == 1
-    # split-K when the 64x64 output grid alone cannot fill 256 CUs (2 workgroups each) and the reduction is long;
-    # thresholds from scripts/gemm_micro.py + rocprofv3 on the step's shapes
-    blocks = -(-M // 64) * -(-N // 64)
-    if splits is None and not trans and A.dtype == torch.bfloat16 and -(-M // 32) * -(-N // 32) <= 256 and K <= 1024:
-        splits = 1            # gemm.hip: 32x32 tiles with eight stages of loads in flight, no split-K pass
     if splits is None:
-        if blocks >= 160:
-            splits = 2 if (K >= 3072 and blocks < 384) else 1
-        else:
-            splits = max(1, min(K // 384, 320 // blocks, 16))
+        splits = gemm_splits(M, N, K, A.dtype, trans)
     ws = torch.empty(splits, M, N, device=A.device, dtype=torch.float32) if splits > 1 else None
-    tag = dict(kind='tn' if trans else 'nt', shape=f'{M}x{N}x{K}', flops=2.0 * M * N * K,
+    tag = lambda: dict(kind='tn' if trans else 'nt', shape=f'{M}x{N}x{K}', flops=2.0 * M * N * K,
                bytes=float((M * K + N * K) * A.element_size() + M * N * out.element_size()))
     L.call('vqa_gemm', L.dt(A), int(trans), M, N, K, A, A.stride(0), B, B.stride(0), out, out.stride(0), L.dt(out),
            bias, rowadd, group, act, int(accumulate), c2, c2.stride(0) if c2 is not None else 0, ws, splits, tag=tag)
     return out
+
+
+def gemm_splits(M, N, K, dtype, trans=False):
+    """split-K when the 64x64 output grid alone cannot fill 256 CUs (2 workgroups each) and the reduction is long;
+    thresholds from scripts/gemm_micro.py + rocprofv3 on the step's shapes"""
+    blocks = -(-M // 64) * -(-N // 64)
+    if not trans and dtype == torch.bfloat16 and -(-M // 32) * -(-N // 32) <= 256 and K <= 1024:
+        return 1              # gemm.hip: 32x32 tiles with eight stages of loads in flight, no split-K pass
+    if blocks >= 160:
+        return 2 if (K >= 3072 and blocks < 384) else 1
+    return max(1, min(K // 384, 320 // blocks, 16))
 
 
 _scratch = {}

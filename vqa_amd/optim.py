@@ -210,7 +210,10 @@ class Trainer:
         mirror = flip and self.model.flip.draw()
         logits = self.model(images, questions, mirror=mirror, dropout_noise=dropout_noise)
         loss = self.criterion(logits, target)
-        loss.backward()
+        # The step is host-bound (~150 launches): with autograd's worker thread off, the backward's Python code runs
+        # on this thread - no hand-over per node (issue time 4.17 -> 3.72 ms per step)
+        with torch.autograd.set_multithreading_enabled(False):
+            loss.backward()
         ops.join_deferred()
         if not self.buckets.active:
             self.flat.collect()

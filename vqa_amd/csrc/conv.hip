@@ -627,8 +627,11 @@ int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
 
 template <typename T, int CK>
 int dispatch_nb(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
-    if (a.Cout % 64 == 0) return launch_igemm<T, CK, 4>(s, a, G, plan_only);
-    if (a.Cout == 32) return launch_igemm<T, CK, 2>(s, a, G, plan_only);
+    // 64-channel output blocks for the multi-chunk kernel (32-channel ones re-stage every patch twice: 56x56 64->64
+    // 0.116 -> 0.150 ms); the single-chunk persistent kernel prefers 32 (165 registers = three waves per SIMD where the
+    // 64-channel form has 238 = two: 58x58 32->64 0.083 -> 0.070 ms)
+    if (a.Cout % 64 == 0 && a.Cin != CK) return launch_igemm<T, CK, 4>(s, a, G, plan_only);
+    if (a.Cout % 32 == 0) return launch_igemm<T, CK, 2>(s, a, G, plan_only);
     if (a.Cout == 16) return launch_igemm<T, CK, 1>(s, a, G, plan_only);
     return plan_only ? -1 : VQA_ERR_ARG;
 }

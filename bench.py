@@ -55,29 +55,80 @@ def make_fixture(tmp, vocab=10000, classes=3129):
     return qpath, lpath
 
 
-def cpu_baseline(hidden, classes, vocab, seconds=20.0):
-    """The CPU oracle's training step (fwd+bwd, fp32, batch 32 = BASELINE.json configs[0]) on this box's host cores."""
+def host_cores():
+    """(physical cores of the machine, logical CPUs this process may run on)."""
+    phys = set()
+    try:
+        pid = cid = None
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('physical id'):
+                pid = ln.split(':')[1].strip()
+            elif ln.startswith('core id'):
+                cid = ln.split(':')[1].strip()
+            elif not ln.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return len(phys) or (os.cpu_count() or 1), usable
+
+
+def cpu_baseline(hidden, classes, vocab, seconds=12.0):
+    """The CPU oracle's training step (fp32, batch 32 = BASELINE.json configs[0]) on this box's host cores:
+    fwd+bwd on the job's CPU share (16 threads per GPU on the pool's boxes; the machine's core count is reported beside
+    it), the same with clip_grad_norm + Adamax (vqa_model.py:259, :266), and one thread for a per-core figure."""
     import torch
     from oracle import vqa_oracle as O
     from vqa_amd import synth
-    threads = min(16, os.cpu_count() or 1)       # the box's CPU share for one GPU is 16
-    torch.set_num_threads(threads)
+    phys, usable = host_cores()
+    threads = min(16, usable)                    # the box's CPU share for one GPU is 16
     B = 32
     sd = synth.state_dict(42, hidden, classes, vocab)
     img, q, t = synth.images(1234, B, 224), synth.questions(1234, B, 14, vocab), synth.targets(1234, B, classes)
-    times = []
-    t_end = time.perf_counter() + seconds
-    for i in range(12):
-        t0 = time.perf_counter()
-        O.train_step_grads(sd, img, q, t, 2, 'max')
-        times.append(time.perf_counter() - t0)
-        if i >= 3 and time.perf_counter() > t_end:
-            break
-    times = sorted(times[2:]) if len(times) > 3 else sorted(times)
-    med = times[len(times) // 2]
+    params = {k: v for k, v in sd.items() if O.is_param(k)}
+
+    def timed(fn, warm, most, budget):
+        times, t_end = [], None
+        for i in range(warm + most):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            if i >= warm:
+                times.append(dt)
+            if i == warm - 1 or (warm == 0 and i == 0):
+                t_end = time.perf_counter() + budget
+            if t_end is not None and len(times) >= 2 and time.perf_counter() > t_end:
+                break
+        times.sort()
+        return times[len(times) // 2], len(times)
+
+    def fwd_bwd():
+        return O.train_step_grads(sd, img, q, t, 2, 'max')
+
+    state = {}
+
+    def full_step():
+        _, _, grads, _ = fwd_bwd()
+        _, clipped = O.clip_grad_norm(grads)
+        O.adamax_step(params, clipped, state)
+
+    torch.set_num_threads(threads)
+    med, n = timed(fwd_bwd, 2, 10, seconds)
+    med_full, n_full = timed(full_step, 1, 4, seconds / 3)
+    torch.set_num_threads(1)
+    med_1, n_1 = timed(fwd_bwd, 0, 2, 0.0)
+    torch.set_num_threads(threads)
     return {'value': round(B / med, 2), 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
             'sample': f'oracle fwd+bwd, fp32, batch {B}, 224x224, T=14, C={classes}, H={hidden}; median of '
-                      f'{len(times)} steps after 2 warm-up'}
+                      f'{n} steps after 2 warm-up',
+            'with_clip_adamax': round(B / med_full, 2), 'with_clip_adamax_steps': n_full,
+            'one_thread': round(B / med_1, 2), 'one_thread_steps': n_1,
+            'host_physical_cores': phys, 'host_usable_cpus': usable}
 
 
 def pmc_traffic(kernel):
@@ -85,7 +136,7 @@ def pmc_traffic(kernel):
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this bench; counters are in KB).  gfx950 correction of
     MI355X_MICROARCH.md (HBM): FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane reads at 64 bytes, so it is
     doubled; WRITE_SIZE is exact for 16/8-byte streaming stores.  None when no profile is committed for the kernel."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_traffic.json')
     try:
         rec = json.load(open(path))[kernel]
         return round((2.0 * rec['FETCH_SIZE'] + rec['WRITE_SIZE']) * 1024.0 / rec['launches'])
@@ -93,19 +144,43 @@ def pmc_traffic(kernel):
         return None
 
 
-# C-ABI entry point -> the device kernel (template family) that does its work
-KERNEL_OF = {'vqa_conv3x3_fwd': 'conv3x3_igemm', 'vqa_conv3x3_wgrad': 'conv3x3_wgrad', 'vqa_gemm': 'gemm_bf16',
-             'vqa_bn_bwd': 'bn_bwd', 'vqa_bn_act_pool_fwd': 'bn_act_pool_fwd'}
+# C-ABI entry point -> the device kernel (template family) that does its work; vqa_conv3x3_fwd launches one of two
+# kernels (its tag says which): the single-chunk persistent one (Cin <= 32: HBM-bound) or the multi-chunk tile kernel
+# (Cin >= 64: MFMA-bound) - two regimes, priced separately
+KERNEL_OF = {'vqa_conv3x3_wgrad': 'conv3x3_wgrad', 'vqa_gemm': 'gemm_bf16', 'vqa_bn_bwd': 'bn_bwd',
+             'vqa_bn_act_pool_fwd': 'bn_act_pool_fwd', 'vqa_conv3x3_first_fwd': 'conv3x3_first_fwd',
+             'vqa_conv3x3_first_wgrad_bn': 'conv3x3_first_wgrad'}
+PMC_NAME = {'conv3x3_igemm_p': 'conv3x3_igemm_p', 'conv3x3_igemm_tile': 'conv3x3_igemm_tile'}
+# SURVEY.md 8(d) floor: every conv output y, every block output a and their two gradients written once and read once,
+# (3,131,328 + 1,982,876) elements per sample at 224x224 / padding 2, 2 bytes each in bf16
+ACT_ELEMS_PER_SAMPLE_224 = 3131328 + 1982876
 
 
-def roofline_leg(trainer, batch):
+def price(r, peak_tflops):
+    """One family's launches against both roofs -> dict with the binding one."""
+    sec = r['ms'] * 1e-3
+    gbs, tfl = r['bytes'] / sec / 1e9, r['flops'] / sec / 1e12
+    bound = 'mfma' if r['flops'] / (peak_tflops * 1e12) > r['bytes'] / (HBM_PEAK_GBS * 1e9) else 'hbm'
+    out = {'bound': bound, 'launches_per_step': r['n'], 'avg_launch_ms': round(r['ms'] / r['n'], 4),
+           'kernel_ms_per_step': round(r['ms'], 3), 'tflops': round(tfl, 2), 'gbs': round(gbs, 1),
+           'algorithmic_bytes_per_launch': round(r['bytes'] / r['n']),
+           'algorithmic_gflop_per_launch': round(r['flops'] / r['n'] / 1e9, 3)}
+    if bound == 'hbm':
+        out.update(achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
+    else:
+        out.update(achieved=round(tfl, 2), peak=peak_tflops, unit='TFLOP/s', frac=round(tfl / peak_tflops, 4))
+    return out
+
+
+def roofline_leg(trainer, batch, precision='bf16'):
     """One extra, instrumented step: HIP events around every C-ABI call on the launching stream (question encoder
-    and weight gradients kept on the main stream for this step, so no launch is timed under a concurrent kernel);
-    picks the device kernel with the largest total time (conv3x3_igemm serves the forward conv AND the data gradient)
-    and prices the sum of its launches against the roofline that binds that sum."""
+    and weight gradients kept on the main stream for this step, so no launch is timed under a concurrent kernel).
+    `roofline` = the device kernel with the largest total time, priced against the roof that binds the sum of ITS
+    launches; `roofline_by_kernel` = the same for every kernel family that carries algorithmic work."""
     from vqa_amd import _lib as L
     from vqa_amd import cnn as CN
     from vqa_amd import vqa_model as VM
+    peak = MFMA_BF16_PEAK_TFLOPS if precision == 'bf16' else MFMA_F32_PEAK_TFLOPS
     side, VM.SIDE_STREAM = VM.SIDE_STREAM, False
     hside, VM.HEAD_WGRAD_STREAM = VM.HEAD_WGRAD_STREAM, False
     wside, CN.WGRAD_STREAM = CN.WGRAD_STREAM, False
@@ -121,33 +196,24 @@ def roofline_leg(trainer, batch):
     rows, fam = {}, {}
     for name, recs in prof.items():
         for ms, tag in recs:
-            for table, key in ((rows, name if not tag else f"{name}[{tag['kind']}]"), (fam, KERNEL_OF.get(name, name))):
+            family = (tag or {}).get('kernel') or KERNEL_OF.get(name, name)
+            for table, key in ((rows, name if not tag else f"{name}[{tag['kind']}]"), (fam, family)):
                 r = table.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
                 r['ms'] += ms
                 r['n'] += 1
                 if tag:
                     r['flops'] += tag['flops']
                     r['bytes'] += tag['bytes']
-    dom = max((k for k in fam if fam[k]['bytes'] > 0), key=lambda k: fam[k]['ms'])
-    r = fam[dom]
-    gbs = r['bytes'] / (r['ms'] * 1e-3) / 1e9
-    tfl = r['flops'] / (r['ms'] * 1e-3) / 1e12
-    # binding roofline of the launches taken together: the one that needs more time at its peak
-    bound = 'mfma' if r['flops'] / (MFMA_BF16_PEAK_TFLOPS * 1e12) > r['bytes'] / (HBM_PEAK_GBS * 1e9) else 'hbm'
-    out = {'kernel': dom, 'bound': bound, 'launches_per_step': r['n'], 'avg_launch_ms': round(r['ms'] / r['n'], 4),
-           'traffic': None, 'tflops': round(tfl, 2), 'gbs': round(gbs, 1),
-           'algorithmic_bytes_per_launch': round(r['bytes'] / r['n']), 'kernel_ms_per_step': round(r['ms'], 3)}
-    out['traffic'] = pmc_traffic(dom)
-    if bound == 'hbm':
-        out.update(achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
-    else:
-        out.update(achieved=round(tfl, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s',
-                   frac=round(tfl / MFMA_BF16_PEAK_TFLOPS, 4))
+    priced = {k: price(r, peak) for k, r in fam.items() if r['bytes'] > 0}
+    dom = max(priced, key=lambda k: fam[k]['ms'])
+    out = dict(kernel=dom, traffic=pmc_traffic(dom), **priced[dom])
+    by_kernel = {k: {kk: v[kk] for kk in ('bound', 'frac', 'achieved', 'unit', 'kernel_ms_per_step', 'launches_per_step')}
+                 for k, v in sorted(priced.items(), key=lambda kv: -fam[kv[0]]['ms'])[:8]}
     out['per_launch'] = [f"{name}[{tag['kind']}] {tag['shape']:>18s} {ms:7.3f} ms {tag['flops'] / ms / 1e9:8.1f} TF/s "
                          f"{tag['bytes'] / ms / 1e6:8.1f} GB/s"
                          for name, recs in prof.items() for ms, tag in recs if tag]
     breakdown = {k: round(v['ms'], 3) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:48]}
-    return out, breakdown, sum(totals.values())
+    return out, by_kernel, breakdown, sum(totals.values())
 
 
 def main():
@@ -306,10 +372,20 @@ def main():
         'step_tflops_algorithmic': round(value * GFLOP_PER_SAMPLE_TRAIN / 1e3, 2),
     }
     # every rank runs the instrumented step (it all-reduces like any other); rank 0 reports its own timings
-    roof, breakdown, dev_ms = roofline_leg(trainer, batch)
+    roof, by_kernel, breakdown, dev_ms = roofline_leg(trainer, batch, args.precision)
     if rank == 0:
         result['roofline'] = roof
+        result['roofline_by_kernel'] = by_kernel
         result['device_ms_in_kernels'] = round(dev_ms, 3)
+        if args.image == 224:
+            # the whole step against both roofs: SURVEY.md 8(d)'s write-once / read-once activation bytes (plus the
+            # f16 images and parameters + gradients + Adamax state) per step time, and the algorithmic FLOPs
+            act = ACT_ELEMS_PER_SAMPLE_224 * 4 * (2 if args.precision == 'bf16' else 4) * B + 150528 * 2 * B + 194e6
+            peak = MFMA_BF16_PEAK_TFLOPS if args.precision == 'bf16' else MFMA_F32_PEAK_TFLOPS
+            result['step_roofline'] = {
+                'algorithmic_bytes_per_step': round(act), 'hbm_frac': round(act / (ms_per_step * 1e-3) / 8e12, 4),
+                'algorithmic_tflops': result['step_tflops_algorithmic'],
+                'mfma_frac': round(result['step_tflops_algorithmic'] / world / peak, 4)}
         if args.breakdown:
             print(json.dumps(breakdown, indent=1), file=sys.stderr)
             for ln in roof.pop('per_launch'):

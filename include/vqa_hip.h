@@ -150,8 +150,12 @@ int vqa_cast_pad(void* stream, int src_dtype, int dst_dtype, const void* src, in
  * loss; the backward skips it. */
 int vqa_embed_fwd(void* stream, int dtype, const long* q, const float* emb, int B, int T, int E, int V, void* x,
                   int ldx);
-/* its backward: demb[q[b][t]] += dx[t*B + b] (demb pre-zeroed). */
-int vqa_embed_bwd(void* stream, const long* q, const float* dx, int B, int T, int E, int V, int lddx, float* demb);
+/* its backward: demb[q[b][t]] += dx[t*B + b] (demb pre-zeroed by the caller), DETERMINISTIC: the tokens are sorted by
+ * (id, position) and every row's occurrences are summed in that order (blocks of 16, then the blocks in order) - no
+ * atomics, the same bits every run.  ws: vqa_embed_bwd_ws_bytes(B, T, E) bytes of scratch (-1 = unsupported size). */
+int vqa_embed_bwd_ws_bytes(int B, int T, int E);
+int vqa_embed_bwd(void* stream, const long* q, const float* dx, int B, int T, int E, int V, int lddx, float* demb,
+                  void* ws);
 /* nn.GRU cell gates (gru.py:104): r, z, n and h' = (1-z) n + z h from the two projections gi, gh ([B][3H], biases
  * included); save = [B][4H] (r, z, n, W_hn h + b_hn) for the backward.  H % 4 == 0 (16-byte accesses). */
 int vqa_gru_gate_fwd(void* stream, int dtype, const float* gi, const float* gh, const float* hprev, int B, int H,

@@ -65,3 +65,36 @@ def test_persistent_matches_per_step(tmp_path, monkeypatch):
     for k in outs[0][1]:
         a, b = outs[0][1][k], outs[1][1][k]
         assert float((a - b).norm() / b.norm()) < 2e-2, k
+
+
+@pytest.mark.parametrize('B,T,E,V,hot', [(256, 14, 300, 10000, 0.4), (64, 30, 300, 82, 0.5), (700, 14, 300, 500, 0.3),
+                                         (5, 3, 6, 7, 0.0), (1, 1, 300, 82, 0.0), (33, 9, 10, 40, 0.9)])
+def test_embedding_backward_is_exact_and_deterministic(B, T, E, V, hot):
+    """vqa_embed_bwd (sorted, no atomics) against the scatter-add in fp64: hot rows (the <pad> row takes `hot` of the
+    tokens), out-of-vocabulary ids (dropped), more tokens than one sort chunk (700 x 14 > 8192), widths that are not a
+    multiple of 4 - and bit-identical on a second run."""
+    from vqa_amd import _lib as L
+    torch.manual_seed(B + T + E)
+    q = torch.randint(0, V, (B, T))
+    q[torch.rand(B, T) < hot] = 1
+    if B * T > 20:
+        q[0, 0], q[-1, -1] = V + 3, -2                       # nn.Embedding would raise: these contribute nothing
+    ldx = (E + 7) // 8 * 8
+    dx = torch.randn(T * B, ldx)
+    want = torch.zeros(V, E, dtype=torch.float64)
+    for b in range(B):
+        for t in range(T):
+            if 0 <= int(q[b, t]) < V:
+                want[int(q[b, t])] += dx[t * B + b, :E].double()
+    outs = []
+    for _ in range(2):
+        demb = torch.zeros(V, E, device='cuda')
+        ws = torch.empty(L.lib().vqa_embed_bwd_ws_bytes(B, T, E), device='cuda', dtype=torch.uint8)
+        L.call('vqa_embed_bwd', q.cuda(), dx.cuda(), B, T, E, V, ldx, demb, ws)
+        outs.append(demb.cpu())
+    assert torch.equal(outs[0], outs[1])
+    scale = float(want.abs().max()) + 1e-30
+    assert float((outs[0].double() - want).abs().max()) < 2e-6 * scale * max(1.0, (hot * B * T) ** 0.5)
+    untouched = torch.ones(V, dtype=torch.bool)
+    untouched[q[(q >= 0) & (q < V)].unique()] = False
+    assert float(outs[0][untouched].abs().max() if untouched.any() else 0.0) == 0.0

@@ -147,10 +147,7 @@ def test_trainer_flat_gradients_and_step(tmp_path):
     names = dict(zip(tr.flat.names, tr.flat.params))
     for k, r in ref.items():
         got = names[k]._vqa_grad_dst.view(r.shape)
-        if k == 'gru.word_embedding.weight':                 # scatter-add by float atomics: order-dependent last bits
-            assert torch.allclose(got, r, rtol=1e-4, atol=1e-6), k
-        else:
-            assert torch.equal(got, r), k                    # same kernels, same bits
+        assert torch.equal(got, r), k                        # same kernels, same bits
     assert float(tr.opt.total_norm) == pytest.approx(float(g['total_norm']), rel=1e-3)
     for k, p in m.named_parameters():
         if k.startswith('cnn.convolutions') and k.endswith('.bias') and int(k.split('.')[2]) in O.CONV_IDX:
@@ -266,10 +263,7 @@ def test_mirror_equals_flipped_batch(prec, tmp_path):
         out.append((logits.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
     assert torch.equal(out[0][0], out[1][0])
     for k in out[0][1]:
-        if k == 'gru.word_embedding.weight':                 # float atomics in the scatter-add
-            assert torch.allclose(out[0][1][k], out[1][1][k], rtol=1e-5, atol=1e-7)
-        else:
-            assert torch.equal(out[0][1][k], out[1][1][k]), k
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
 
 
 @pytest.mark.parametrize('prec', ['bf16', 'fp32'])
@@ -294,7 +288,4 @@ def test_side_streams_do_not_change_results(prec, tmp_path, monkeypatch):
         out.append((logits.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
     assert torch.equal(out[0][0], out[1][0])
     for k in out[0][1]:
-        if k == 'gru.word_embedding.weight':                 # float atomics in the scatter-add
-            assert torch.allclose(out[0][1][k], out[1][1][k], rtol=1e-5, atol=1e-7)
-        else:
-            assert torch.equal(out[0][1][k], out[1][1][k]), k
+        assert torch.equal(out[0][1][k], out[1][1][k]), k

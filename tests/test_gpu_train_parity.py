@@ -290,10 +290,7 @@ def test_gradient_accumulation_with_side_streams(prec, tmp_path, monkeypatch):
         out.append((twice, {k: p.grad.detach().clone() for k, p in m.named_parameters()}, seen[0]))
     for a, b in zip(out[0][:2], out[1][:2]):
         for k in a:
-            if k == 'gru.word_embedding.weight' and not torch.equal(a[k], b[k]):
-                assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7)      # (float atomics, if still in use)
-            else:
-                assert torch.equal(a[k], b[k]), k
+            assert torch.equal(a[k], b[k]), k
     assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][2], out[0][1]['fc.weight_v'])
 
 

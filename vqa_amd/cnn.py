@@ -94,11 +94,14 @@ def pack_all(jobs, dtype, scales=None):
     return outs
 
 
-def _conv_tag(kind, B, OH, OW, cin_real, cout_real, x, y_elems_bytes, w_bytes):
+def _conv_tag(kind, B, OH, OW, cin_real, cout_real, x, y_elems_bytes, w_bytes, kernel=None):
     """Algorithmic work of one conv launch for bench.py's roofline leg: MACs as the reference writes them
     (real channel counts), bytes = input read once + output written once + weights."""
-    return dict(kind=kind, shape=f'{OH}x{OW} {cin_real}->{cout_real}', flops=2.0 * B * OH * OW * 9 * cin_real * cout_real,
-                bytes=float(x.numel() * x.element_size() + y_elems_bytes + w_bytes))
+    tag = dict(kind=kind, shape=f'{OH}x{OW} {cin_real}->{cout_real}', flops=2.0 * B * OH * OW * 9 * cin_real * cout_real,
+               bytes=float(x.numel() * x.element_size() + y_elems_bytes + w_bytes))
+    if kernel:
+        tag['kernel'] = kernel
+    return tag
 
 
 def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', relu=False, in_coeffs=None, bst=None):
@@ -116,7 +119,8 @@ def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', rel
     cr = cin if cin_real is None else cin_real
     # (algorithmic bytes of the launch: + the lower layer's y when its BatchNorm-backward sums are formed here)
     tag = lambda: _conv_tag(kind, B, OH, OW, cr, cout, x, y.numel() * y.element_size() * (2 if bst else 1),
-                            wpk.numel() * wpk.element_size())
+                            wpk.numel() * wpk.element_size(),
+                            kernel='conv3x3_igemm_p' if cin == _ck(cin, x.dtype) else 'conv3x3_igemm_tile')
     isc, ish = in_coeffs if in_coeffs is not None else (None, None)
     by, bcoef = bst if bst else (None, None)
     if bst:

@@ -240,15 +240,6 @@ __global__ void embed_fwd(const long* q, const float* emb, int B, int Tn, int E,
     for (int e = threadIdx.x; e < ldx; e += blockDim.x)
         x[(long)row * ldx + e] = from_f32<T>(e < E ? (ok ? emb[id * E + e] : NAN) : 0.f);
 }
-// demb[q[b][t]][e] += dx[t*B+b][e]
-__global__ void embed_bwd(const long* q, const float* dx, int B, int Tn, int E, int V, int lddx, float* demb) {
-    const int row = blockIdx.x;
-    const int t = row / B, b = row % B;
-    const long id = q[(long)b * Tn + t];
-    if (id < 0 || id >= V) return;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) atomicAdd(&demb[id * E + e], dx[(long)row * lddx + e]);
-}
-
 // ---------------------------------------------------------------------------------------- GRU gates
 // gi, gh: [B][3H] (gate rows r,z,n; biases already added).  h' = (1-z) n + z h.   saved: r, z, n, hn = gh_n.
 // One thread = 4 consecutive hidden units of one sample (float4 loads, 8- or 16-byte stores; H % 4 == 0): with one
@@ -794,14 +785,6 @@ extern "C" int vqa_embed_fwd(void* stream, int dtype, const long* q, const float
     if (B < 1 || T < 1 || E < 1 || V < 1 || ldx < E) return VQA_ERR_ARG;
     BY_T(dtype, hipLaunchKernelGGL(embed_fwd<bf16>, dim3(B * T), dim3(128), 0, ST, q, emb, B, T, E, V, (bf16*)x, ldx),
          hipLaunchKernelGGL(embed_fwd<float>, dim3(B * T), dim3(128), 0, ST, q, emb, B, T, E, V, (float*)x, ldx));
-    CHECK_LAUNCH();
-    return VQA_OK;
-}
-
-extern "C" int vqa_embed_bwd(void* stream, const long* q, const float* dx, int B, int T, int E, int V, int lddx,
-                             float* demb) {
-    if (B < 1 || T < 1 || E < 1 || V < 1) return VQA_ERR_ARG;
-    hipLaunchKernelGGL(embed_bwd, dim3(B * T), dim3(128), 0, ST, q, dx, B, T, E, V, lddx, demb);
     CHECK_LAUNCH();
     return VQA_OK;
 }

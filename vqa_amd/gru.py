@@ -117,7 +117,8 @@ class _GruFunction(torch.autograd.Function):
         dx = ops.gemm(dgi, wih_T)                                # [T*B, E] fp32
         demb = ops.grad_dst(emb)
         demb = torch.zeros_like(emb) if demb is None else demb.zero_()
-        L.call('vqa_embed_bwd', q, dx, B, T, E, emb.shape[0], dx.stride(0), demb)
+        ws = torch.empty(L.lib().vqa_embed_bwd_ws_bytes(B, T, E), device=dev, dtype=torch.uint8)
+        L.call('vqa_embed_bwd', q, dx, B, T, E, emb.shape[0], dx.stride(0), demb, ws)
         return None, None, demb, dw_ih, dw_hh, db_ih, db_hh
 
 

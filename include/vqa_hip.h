@@ -120,6 +120,15 @@ int vqa_bn_bwd_finalize(void* stream, const float* part, int rows, int C, double
 int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
              void* C, int ldc, int c_dtype, const float* bias, const float* rowadd, int rowadd_group, int act,
              int accumulate, void* C2, int ldc2, float* splitk_ws, int splits);
+/* The classifier GEMM with the loss in its epilogue (vqa_model.py:103 self.fc(...) + :215 BCEWithLogitsLoss(sum)):
+ * logits [M][ldc] f32 = A[M,K] * W[N,K]^T written once, loss[0] and dlogits [M][ldd] = sigmoid(logits) - target formed
+ * from the accumulators (no second pass over logits / targets).  target: dense f32 [M][ldt]; or NULL with the sparse
+ * form labels int64 / scores f32 [M][L] (as vqa_bce_sum_sparse); part: vqa_fc_bce_part(M, N) doubles of scratch
+ * (per-workgroup partials, summed in a fixed order). */
+int vqa_fc_bce_part(int M, int N);
+int vqa_fc_bce(void* stream, int dtype, int M, int N, int K, const void* A, int lda, const void* W, int ldw,
+               float* logits, int ldc, const float* target, int ldt, const long* labels, const float* scores, int L,
+               float* dlogits, int ldd, double* part, float* loss);
 /* out[0] = <a, b> (f32 data, f64 accumulation); part = 256 doubles of scratch. */
 int vqa_dot(void* stream, const float* a, const float* b, long n, double* part, float* out);
 /* out[n] = sum_m x[m][n] (bias gradients); `slabs` row slabs go through scratch [slabs][N] (NULL if slabs == 1). */
@@ -139,9 +148,10 @@ int vqa_wn_fwd_all(void* stream, int dtype, int n, const void* const* v, const v
                    void* const* wt, const int* dims, float* sumsq, double* part);
 int vqa_wn_bwd_all(void* stream, int n, const void* const* dw, const void* const* v, const void* const* g,
                    void* const* dv, void* const* dg, const int* dims, const float* sumsq, double* part);
-/* dtype conversion with zero-padded leading dimension. */
+/* dtype conversion with zero-padded leading dimension; scale (device scalar, may be NULL) multiplies every element (the
+ * incoming gradient of a scalar loss, without a host read). */
 int vqa_cast_pad(void* stream, int src_dtype, int dst_dtype, const void* src, int M, int N, int lds, void* dst,
-                 int ldd);
+                 int ldd, const float* scale);
 
 /* ---------------------------------------------------------------- question encoder (gru.py:48-52, :101-106) */
 

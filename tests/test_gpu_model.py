@@ -289,3 +289,44 @@ def test_side_streams_do_not_change_results(prec, tmp_path, monkeypatch):
     assert torch.equal(out[0][0], out[1][0])
     for k in out[0][1]:
         assert torch.equal(out[0][1][k], out[1][1][k]), k
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('sparse', [False, True])
+def test_fused_classifier_loss_equals_the_criterion(prec, sparse, tmp_path):
+    """VQA.forward_loss (the classifier GEMM with the sigmoid-BCE epilogue, vqa_model.py:103 + :215) against forward() +
+    SoftScoreBCELoss: the same logits bit for bit, the same gradient of the loss w.r.t. the logits bit for bit (hence
+    every parameter gradient), the loss up to the summation order of its partials; with a loss scale other than 1 and
+    with dense and sparse targets; and against the oracle's BCE."""
+    import vqa_model
+    from oracle import vqa_oracle as O
+    c = load_case('h64_p5_max')
+    img, q, t = c['images'].cuda(), c['questions'].cuda(), c['targets'].cuda()
+    tgt = t
+    if sparse:
+        L_ = 10
+        labels = torch.full((t.shape[0], L_), -1, dtype=torch.int64)
+        scores = torch.zeros(t.shape[0], L_)
+        for b in range(t.shape[0]):
+            nz = c['targets'][b].nonzero().flatten()
+            labels[b, :len(nz)] = nz
+            scores[b, :len(nz)] = c['targets'][b, nz]
+        tgt = (labels.cuda(), scores.cuda())
+    out = []
+    for fused in (True, False):
+        m = build_model(c, tmp_path, prec).cuda().train()
+        if fused:
+            logits, loss = m.forward_loss(img, q, tgt)
+        else:
+            logits = m(img, q)
+            loss = vqa_model.SoftScoreBCELoss()(logits, tgt)
+        (loss * 0.37).backward()
+        out.append((logits.detach(), float(loss.detach()), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert torch.equal(out[0][0], out[1][0])
+    assert out[0][1] == pytest.approx(out[1][1], rel=1e-6)
+    assert out[0][1] == pytest.approx(float(O.bce_sum(out[0][0].cpu(), c['targets'])), rel=1e-5)
+    for k in out[0][2]:
+        a, b = out[0][2][k], out[1][2][k]
+        # (the unfused path multiplies sigmoid(x) - t by the loss scale in fp32 before the bf16 cast, the fused one
+        # inside the cast: the same fp32 product, the same rounding)
+        assert torch.equal(a, b), k

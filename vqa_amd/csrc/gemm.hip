@@ -23,6 +23,13 @@ struct GemmArgs {
     int act, accumulate;
     bf16* C2; int ldc2;
     float* ws; int kper;   // split-K: grid.z slices of `kper` k each write raw sums to ws[z][M][N]
+    // act == 2: the classifier GEMM's sigmoid-BCE epilogue (vqa_model.py:103 + :215).  C = logits as usual; besides,
+    // dlogits[m][n] = sigmoid(x) - t and one partial of sum max(x,0) - x t + log1p(exp(-|x|)) per workgroup
+    // (loss_part[blockIdx.y * gridDim.x + blockIdx.x], summed in fixed order by the caller).  target may be null
+    // (t = 0: sparse targets, whose few (label, score) terms are applied afterwards).
+    const float* target; int ldt;
+    float* dlogits; int ldd;
+    double* loss_part;
 };
 
 template <typename T>
@@ -46,8 +53,8 @@ __device__ __forceinline__ uint4 load_row_chunk(const T* base, long row, int ld,
 
 // bias / row-broadcast add / ReLU / accumulate, then a 4-wide store of C (and the optional bf16 copy C2)
 template <typename TC>
-__device__ __forceinline__ void epilogue_store(const GemmArgs& g, TC* C, int m, int n, const f32x4& a, bool vec_ok) {
-    float v[4];
+__device__ __forceinline__ float epilogue_store(const GemmArgs& g, TC* C, int m, int n, const f32x4& a, bool vec_ok) {
+    float v[4], loss = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float x = a[e];
@@ -57,6 +64,12 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, TC* C, int m, 
             if (g.rowadd) x += g.rowadd[(long)(m / g.rowadd_group) * g.N + ne];
             if (g.act == 1) x = fmaxf(x, 0.f);
             if (g.accumulate) x += to_f32(C[(long)m * g.ldc + ne]);
+            if (g.act == 2) {                      // the arithmetic of bce_partial (misc.hip), element for element
+                const float t = g.target ? g.target[(long)m * g.ldt + ne] : 0.f;
+                const float ex = __expf(-fabsf(x));
+                loss += fmaxf(x, 0.f) - x * t + log1pf(ex);
+                g.dlogits[(long)m * g.ldd + ne] = (x >= 0.f ? 1.f / (1.f + ex) : ex / (1.f + ex)) - t;
+            }
         }
         v[e] = x;
     }
@@ -71,6 +84,16 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, TC* C, int m, 
                 if (g.C2) g.C2[(long)m * g.ldc2 + n + e] = (bf16)v[e];
             }
     }
+    return loss;
+}
+
+// act == 2: the workgroup's loss partial (fixed order: lanes by shuffle, the four waves in order); red = 4 doubles of LDS
+__device__ __forceinline__ void bce_block_partial(const GemmArgs& g, float lsum, double* red) {
+    double s = wave_sum_d((double)lsum);
+    __syncthreads();                               // (the staging LDS may still be read by a slower wave)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) g.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 template <typename T, typename TC, bool TN>
@@ -150,6 +173,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     TC* C = static_cast<TC*>(g.C);
     const bool vec_ok = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                         (g.C2 == nullptr || g.ldc2 % 4 == 0);
+    float lsum = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 32 + i * 16 + r;
@@ -158,9 +182,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 32 + j * 16 + q * 4;
             if (n >= g.N) continue;
-            epilogue_store<TC>(g, C, m, n, acc[i][j], vec_ok);
+            lsum += epilogue_store<TC>(g, C, m, n, acc[i][j], vec_ok);
         }
     }
+    if (g.act == 2) bce_block_partial(g, lsum, reinterpret_cast<double*>(lds));
 }
 
 
@@ -327,7 +352,7 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
     TC* C = static_cast<TC*>(g.C);
     const bool vec_ok = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                         (g.C2 == nullptr || (g.ldc2 % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C2) & 7) == 0));
-    if (vec_ok && n0 + BN_ <= g.N && (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0) {
+    if (vec_ok && n0 + BN_ <= g.N && (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0 && g.act != 2) {
         // Whole-tile case: after the MFMAs a lane owns 4 consecutive n of ONE m, so a store instruction would scatter
         // 16 rows x 32- or 64-byte pieces.  Each wave passes its 16 m x (TNT*16) n block through LDS (free after the
         // loop's last barrier) and writes whole row segments: 128 (bf16) or 256 (f32) contiguous bytes per row.
@@ -378,6 +403,7 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
         }
         return;
     }
+    float lsum = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + (wm * TM + i) * 16 + r;
@@ -386,9 +412,10 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
         for (int j = 0; j < TNT; ++j) {
             const int n = n0 + (wn * TNT + j) * 16 + q * 4;
             if (n >= g.N) continue;
-            epilogue_store<TC>(g, C, m, n, acc[i][j], vec_ok);
+            lsum += epilogue_store<TC>(g, C, m, n, acc[i][j], vec_ok);
         }
     }
+    if (g.act == 2) bce_block_partial(g, lsum, reinterpret_cast<double*>(dl));
 }
 
 // C = epilogue(sum_z ws[z]) in fixed slice order.  VEC4: four consecutive columns per thread (N, ldc, ldc2 multiples
@@ -503,11 +530,68 @@ extern "C" int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K,
     const int kc = dtype == VQA_BF16 ? 128 : 16;   // split boundaries on whole pipeline stages
     const int kper = ((K + splits - 1) / splits + kc - 1) / kc * kc;
     splits = splits > 1 ? (K + kper - 1) / kper : 1;
+    if (act != 0 && act != 1) return VQA_ERR_ARG;
     GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, bias, rowadd, rowadd_group, act, accumulate,
-               static_cast<bf16*>(C2), ldc2, splits > 1 ? splitk_ws : nullptr, kper};
+               static_cast<bf16*>(C2), ldc2, splits > 1 ? splitk_ws : nullptr, kper, nullptr, 0, nullptr, 0, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == VQA_F32 && c_dtype == VQA_F32) return launch<float, float>(s, trans, g, splits);
     if (dtype == VQA_BF16 && c_dtype == VQA_F32) return launch<bf16, float>(s, trans, g, splits);
     if (dtype == VQA_BF16 && c_dtype == VQA_BF16) return launch<bf16, bf16>(s, trans, g, splits);
     return VQA_ERR_ARG;
+}
+
+// ---- classifier GEMM with the sigmoid-BCE epilogue ---------------------------------------------------------------------
+namespace {
+// sparse soft-score targets: the (label, score) slots of each row after the target-free epilogue pass
+__global__ void fc_bce_sparse_fix(const float* x, int ldx, const long* labels, const float* scores, int M, int N, int L,
+                                  float* dl, int ldd, double* rowfix) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= M) return;
+    double s = 0.0;
+    for (int l = lane; l < L; l += 64) {
+        const long lb = labels[(long)b * L + l];
+        if (lb >= 0 && lb < N) {                           // labels are distinct within a row: no two lanes share dl[lb]
+            const float sc = scores[(long)b * L + l];
+            s -= (double)(x[(long)b * ldx + lb] * sc);
+            dl[(long)b * ldd + lb] -= sc;
+        }
+    }
+    s = wave_sum_d(s);
+    if (lane == 0) rowfix[b] = s;
+}
+__global__ void fc_bce_final(const double* part, int n, float* out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) out[0] = (float)s;
+}
+}  // namespace
+
+// logits = A[M,K] * W[N,K]^T (the weight-normed fc of vqa_model.py:103, no bias) with the loss of vqa_model.py:215
+// formed in the GEMM's epilogue: loss[0] = BCEWithLogits(sum), dlogits = sigmoid(logits) - target; the logits are
+// written once and never re-read.  target: dense f32 [M][ldt], or NULL with labels / scores [M][L] (sparse form, see
+// vqa_bce_sum_sparse), or all NULL (t = 0).  part: vqa_fc_bce_part(M, N) doubles of scratch.
+extern "C" int vqa_fc_bce_part(int M, int N) { return ((M + 31) / 32) * ((N + 31) / 32) + M; }
+extern "C" int vqa_fc_bce(void* stream, int dtype, int M, int N, int K, const void* A, int lda, const void* W, int ldw,
+                          float* logits, int ldc, const float* target, int ldt, const long* labels, const float* scores,
+                          int L, float* dlogits, int ldd, double* part, float* loss) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !logits || !dlogits || !part || !loss) return VQA_ERR_ARG;
+    if (target && labels) return VQA_ERR_ARG;
+    if (labels && (!scores || L < 1)) return VQA_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int cap = vqa_fc_bce_part(M, N);
+    if (hipMemsetAsync(part, 0, (size_t)cap * sizeof(double), s) != hipSuccess) return VQA_ERR_LAUNCH;
+    GemmArgs g{M, N, K, A, lda, W, ldw, logits, ldc, nullptr, nullptr, 1, 2, 0, nullptr, 0, nullptr, K,
+               target, ldt, dlogits, ldd, part};
+    int st;
+    if (dtype == VQA_F32) st = launch<float, float>(s, 0, g, 1);
+    else if (dtype == VQA_BF16) st = launch<bf16, float>(s, 0, g, 1);
+    else return VQA_ERR_ARG;
+    if (st != VQA_OK) return st;
+    if (labels)
+        hipLaunchKernelGGL(fc_bce_sparse_fix, dim3((M + 3) / 4), dim3(256), 0, s, logits, ldc, labels, scores, M, N, L,
+                           dlogits, ldd, part + (cap - M));
+    hipLaunchKernelGGL(fc_bce_final, dim3(1), dim3(64), 0, s, part, cap, loss);
+    CHECK_LAUNCH();
+    return VQA_OK;
 }

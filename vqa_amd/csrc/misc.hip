@@ -202,8 +202,10 @@ __global__ __launch_bounds__(256) void wn_bwd_all(WnJobs j) {
 // cast / pad: dst[m][0..ldd) = src[m][0..N) then zeros.  VEC4: four consecutive elements per thread (N, lds, ldd
 // multiples of 4 and 16-byte aligned bases: the entry checks), else one.
 template <typename TS, typename TD, bool VEC4>
-__global__ void cast_pad(const TS* __restrict__ src, int M, int N, int lds, TD* __restrict__ dst, int ldd) {
+__global__ void cast_pad(const TS* __restrict__ src, int M, int N, int lds, TD* __restrict__ dst, int ldd,
+                         const float* __restrict__ scale) {
     constexpr int V = VEC4 ? 4 : 1;
+    const float sc = scale ? scale[0] : 1.f;
     const int ldv = ldd / V;
     const long total = (long)M * ldv;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -220,9 +222,13 @@ __global__ void cast_pad(const TS* __restrict__ src, int M, int N, int lds, TD* 
                     for (int e = 0; e < 4; ++e) v[e] = (float)t[e];
                 }
             }
+            if (scale) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= sc;
+            }
             store4<TD>(dst + m * ldd + n, v);
         } else {
-            dst[m * ldd + n] = from_f32<TD>(n < N ? to_f32(src[m * lds + n]) : 0.f);
+            dst[m * ldd + n] = from_f32<TD>(n < N ? to_f32(src[m * lds + n]) * sc : 0.f);
         }
     }
 }
@@ -761,15 +767,15 @@ extern "C" int vqa_wn_bwd_all(void* stream, int n, const void* const* dw, const 
 }
 
 extern "C" int vqa_cast_pad(void* stream, int src_dtype, int dst_dtype, const void* src, int M, int N, int lds,
-                            void* dst, int ldd) {
+                            void* dst, int ldd, const float* scale) {
     const bool v4 = N % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
     const long items = (long)M * (v4 ? ldd / 4 : ldd);
     dim3 grid((unsigned)((items + 255) / 256 > 0 ? (items + 255) / 256 : 1));     // one item per thread
 #define GO(TS, TD)                                                                                                  \
     do {                                                                                                            \
-        if (v4) hipLaunchKernelGGL((cast_pad<TS, TD, true>), grid, dim3(256), 0, ST, (const TS*)src, M, N, lds, (TD*)dst, ldd); \
-        else hipLaunchKernelGGL((cast_pad<TS, TD, false>), grid, dim3(256), 0, ST, (const TS*)src, M, N, lds, (TD*)dst, ldd);   \
+        if (v4) hipLaunchKernelGGL((cast_pad<TS, TD, true>), grid, dim3(256), 0, ST, (const TS*)src, M, N, lds, (TD*)dst, ldd, scale); \
+        else hipLaunchKernelGGL((cast_pad<TS, TD, false>), grid, dim3(256), 0, ST, (const TS*)src, M, N, lds, (TD*)dst, ldd, scale);   \
     } while (0)
     if (src_dtype == VQA_F32 && dst_dtype == VQA_BF16) GO(float, bf16);
     else if (src_dtype == VQA_F32 && dst_dtype == VQA_F32) GO(float, float);

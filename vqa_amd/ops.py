@@ -114,15 +114,39 @@ def colsum(x, M=None, N=None, out=None):
     return out
 
 
-def cast_pad(src, dtype, ldd=None):
-    """[M,N] -> contiguous [M,ldd] in `dtype`, zero-padded columns; returns the [M,N] view."""
+def cast_pad(src, dtype, ldd=None, scale=None):
+    """[M,N] -> contiguous [M,ldd] in `dtype`, zero-padded columns; returns the [M,N] view.
+    scale: device scalar multiplied in (the incoming gradient of a scalar loss, no host read)."""
     M, N = src.shape
     ldd = N if ldd is None else ldd
-    if src.dtype == dtype and ldd == src.stride(0):
+    if src.dtype == dtype and ldd == src.stride(0) and scale is None:
         return src
     dst = torch.empty(M, ldd, device=src.device, dtype=dtype)
-    L.call('vqa_cast_pad', L.dt(src), L.dt(dst), src, M, N, src.stride(0), dst, ldd)
+    L.call('vqa_cast_pad', L.dt(src), L.dt(dst), src, M, N, src.stride(0), dst, ldd, scale)
     return dst[:, :N]
+
+
+def fc_bce(x, W, target):
+    """The classifier GEMM with the loss in its epilogue (reference vqa_model.py:103 + :215): x [B,H] and W [C,H] in the
+    MFMA dtype, target dense fp32 [B,C] or the sparse pair (labels, scores) -> (logits fp32 [B,C], loss [1],
+    dlogits = sigmoid(logits) - target)."""
+    B, H = x.shape
+    C = W.shape[0]
+    dev = x.device
+    logits = torch.empty(B, C, device=dev, dtype=torch.float32)
+    dl = torch.empty(B, C, device=dev, dtype=torch.float32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    part = torch.empty(L.lib().vqa_fc_bce_part(B, C), device=dev, dtype=torch.float64)
+    sp = _sparse(target)
+    if sp is not None:
+        dense, ldt, labels, scores, nl = None, 0, sp[0], sp[1], sp[0].shape[1]
+    else:
+        dense = target.contiguous()
+        assert dense.dtype == torch.float32 and tuple(dense.shape) == (B, C)
+        ldt, labels, scores, nl = C, None, None, 0
+    L.call('vqa_fc_bce', L.dt(x), B, C, H, x, x.stride(0), W, W.stride(0), logits, C, dense, ldt, labels, scores, nl,
+           dl, C, part, loss)
+    return logits, loss, dl
 
 
 def weight_norm_fwd(v, g, dtype, transpose=True):

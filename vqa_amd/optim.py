@@ -161,6 +161,8 @@ class FlatAdamax:
 
 
 STEP_PRIORITY = os.environ.get('VQA_STEP_PRIORITY', '1') != '0'
+# the loss formed in the classifier GEMM's epilogue (VQA.forward_loss) instead of a criterion pass over the logits
+FUSED_LOSS = os.environ.get('VQA_FUSED_LOSS', '1') != '0'
 _STEP_STREAMS = {}
 
 
@@ -208,8 +210,11 @@ class Trainer:
         self.opt.zero_grad()
         # the reference flips the batch tensor (vqa_model.py:250); same coin, but the first conv reads it mirrored
         mirror = flip and self.model.flip.draw()
-        logits = self.model(images, questions, mirror=mirror, dropout_noise=dropout_noise)
-        loss = self.criterion(logits, target)
+        if FUSED_LOSS:
+            _, loss = self.model.forward_loss(images, questions, target, mirror=mirror, dropout_noise=dropout_noise)
+        else:
+            logits = self.model(images, questions, mirror=mirror, dropout_noise=dropout_noise)
+            loss = self.criterion(logits, target)
         # The step is host-bound (~150 launches): with autograd's worker thread off, the backward's Python code runs
         # on this thread - no hand-over per node (issue time 4.17 -> 3.72 ms per step)
         with torch.autograd.set_multithreading_enabled(False):

@@ -75,11 +75,13 @@ HEAD_WGRAD_STREAM = os.environ.get('VQA_HEAD_WGRAD_STREAM', '1') != '0'
 
 
 class _HeadFunction(torch.autograd.Function):
-    """(v [B,k,D] fp32, q [B,H] fp32, weights) -> logits [B,C] fp32."""
+    """(v [B,k,D] fp32, q [B,H] fp32, weights) -> (logits [B,C] fp32, loss or None).
+    With `target` (dense [B,C] or the sparse pair) the classifier GEMM forms the sum-BCE loss and sigmoid(x) - t in its
+    epilogue (ops.fc_bce): the second output is the loss, and the backward starts from the saved gradient."""
 
     @staticmethod
-    def forward(ctx, v, q, dtype, masks, g_att, v_att, b_att, g_s, v_s, g_img, v_img, b_img, g_q, v_q, b_q, g_last,
-                v_last, b_last, g_fc, v_fc):
+    def forward(ctx, v, q, dtype, masks, target, g_att, v_att, b_att, g_s, v_s, g_img, v_img, b_img, g_q, v_q, b_q,
+                g_last, v_last, b_last, g_fc, v_fc):
         B, K, D = v.shape
         H, C = v_q.shape[0], v_fc.shape[0]
         dev = v.device
@@ -109,29 +111,44 @@ class _HeadFunction(torch.autograd.Function):
         else:
             m = ops.gemm(m0, W_last, bias=b_last, act=1)
             L.call('vqa_mask_mul', L.dt(m_t), m, mask2, B * H, m_t)
-        logits = ops.gemm(m_t, W_fc)
+        if target is None:
+            logits, loss, dl = ops.gemm(m_t, W_fc), None, None
+        else:
+            logits, loss, dl = ops.fc_bce(m_t, W_fc, target)
+            loss = loss.reshape(())
         ctx.save_for_backward(v, q_t, v_t, a, w_s, p, vhat_t, fv, fq, m0, m, m_t, W_att_T, W_img_T, W_q_T, W_last_T,
                               W_fc_T, ss, g_att, v_att, g_s, v_s, g_img, v_img,
                               g_q, v_q, g_last, v_last, g_fc, v_fc, b_att, b_img, b_q, b_last,
-                              *[t for t in masks if t is not None])
+                              *[t for t in masks if t is not None], *([dl] if dl is not None else []))
         ctx.dims, ctx.dtype, ctx.has_masks = (B, K, D, H, C), dtype, (mask1 is not None, mask2 is not None)
-        return logits
+        ctx.fused_loss = dl is not None
+        ctx.set_materialize_grads(False)
+        return logits, loss
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, dlogits, dloss=None):
         (v, q_t, v_t, a, w_s, p, vhat_t, fv, fq, m0, m, m_t, W_att_T, W_img_T, W_q_T, W_last_T, W_fc_T, ss,
          g_att, v_att, g_s, v_s, g_img, v_img, g_q, v_q, g_last, v_last, g_fc,
          v_fc, b_att, b_img, b_q, b_last) = ctx.saved_tensors[:34]
         extra = list(ctx.saved_tensors[34:])
         mask1 = extra.pop(0) if ctx.has_masks[0] else None
         mask2 = extra.pop(0) if ctx.has_masks[1] else None
+        dl_saved = extra.pop(0) if ctx.fused_loss else None
         B, K, D, H, C = ctx.dims
-        dtype, dev = ctx.dtype, dlogits.device
+        dtype, dev = ctx.dtype, v.device
         new = lambda *s, dt=dtype: torch.empty(*s, device=dev, dtype=dt)
 
         ops.defer_reset()
         # ---- data path first: what the image and question encoders wait for
-        dl_t = ops.cast_pad(dlogits.contiguous(), dtype, ops.pad8(C))            # [B,C] (padded rows)
+        if dl_saved is not None and dloss is not None and dlogits is None:
+            # the loss came out of the classifier's epilogue: d logits = (sigmoid(x) - t) * d loss, scaled in the cast
+            dl_t = ops.cast_pad(dl_saved, dtype, ops.pad8(C), scale=dloss.reshape(1).float())
+        else:
+            if dl_saved is not None and dloss is not None:               # the logits fed something else as well
+                dlogits = dlogits + dl_saved * dloss
+            if dlogits is None:
+                dlogits = torch.zeros(B, C, device=dev, dtype=torch.float32)
+            dl_t = ops.cast_pad(dlogits.contiguous(), dtype, ops.pad8(C))        # [B,C] (padded rows)
         dm = ops.gemm(dl_t, W_fc_T)                                              # [B,H]
         dpre_last = new(B, H)
         L.call('vqa_relu_bwd', L.dt(dpre_last), dm, m, mask2, B * H, dpre_last)
@@ -195,8 +212,8 @@ class _HeadFunction(torch.autograd.Function):
         else:
             wn, db_att, db_img, db_q, db_last = weights()
         (dg_att, dv_att), (dg_s, dv_s), (dg_img, dv_img), (dg_q, dv_q), (dg_last, dv_last), (dg_fc, dv_fc) = wn
-        return (dv.reshape(B, K, D), dq, None, None, dg_att, dv_att, db_att, dg_s, dv_s, dg_img, dv_img, db_img, dg_q,
-                dv_q, db_q, dg_last, dv_last, db_last, dg_fc, dv_fc)
+        return (dv.reshape(B, K, D), dq, None, None, None, dg_att, dv_att, db_att, dg_s, dv_s, dg_img, dv_img, db_img,
+                dg_q, dv_q, db_q, dg_last, dv_last, db_last, dg_fc, dv_fc)
 
 
 class VQA(nn.Module):
@@ -245,7 +262,15 @@ class VQA(nn.Module):
         keep = 1.0 - self.dropout_p
         return torch.empty(B, self.hidden_dim, device=dev).bernoulli_(keep).div_(keep)
 
-    def forward(self, images_batch, questions_batch, mirror=False, dropout_noise=None):
+    def forward_loss(self, images_batch, questions_batch, target, mirror=False, dropout_noise=None):
+        """forward() and the reference's criterion (nn.BCEWithLogitsLoss(reduction='sum'), vqa_model.py:215, :255) in
+        one: the classifier GEMM's epilogue forms the loss and its gradient, so the logits are written once and never
+        re-read (BASELINE.json north_star: "one MFMA GEMM followed by a fused sigmoid-BCE epilogue").  forward() itself
+        is unchanged - the reference's loop calls the model and the criterion separately, and that keeps working.
+        target: dense fp32 [B,C] or the sparse pair (labels, scores).  Returns (logits, loss)."""
+        return self.forward(images_batch, questions_batch, mirror, dropout_noise, _target=target)
+
+    def forward(self, images_batch, questions_batch, mirror=False, dropout_noise=None, _target=None):
         # mirror=True: the batch as model.flip would have flipped it, without the flipped copy (Trainer.step)
         # dropout_noise=(n1, n2): the two nn.Dropout noise tensors [B,H] (keep / (1-p)) of vqa_model.py:101 / :103
         # given by the caller instead of drawn here (parity tests replay the reference's recorded draws)
@@ -266,11 +291,12 @@ class VQA(nn.Module):
         else:
             images_representation = self.cnn(images_batch, mirror)
             questions_representation = self.gru(questions_batch)
-        return self.head(images_representation, questions_representation, dropout_noise)
+        return self.head(images_representation, questions_representation, dropout_noise, _target)
 
-    def head(self, images_representation, questions_representation, dropout_noise=None):
+    def head(self, images_representation, questions_representation, dropout_noise=None, target=None):
         """Attention + fusion + classifier (vqa_model.py:83-103) on given encoder outputs v [B,k,256], q [B,H] (fp32):
-        the second half of forward(), callable on its own (parity tests feed it the oracle's encoder outputs)."""
+        the second half of forward(), callable on its own (parity tests feed it the oracle's encoder outputs).
+        With `target` it returns (logits, loss) - see forward_loss()."""
         dtype = torch.bfloat16 if self.precision == 'bf16' else torch.float32
         B, dev = images_representation.shape[0], images_representation.device
         if dropout_noise is not None:
@@ -279,10 +305,13 @@ class VQA(nn.Module):
         else:
             masks = (self._dropout_mask(B, dev), self._dropout_mask(B, dev))
         a, s, i, qq, l, f = (getattr(self, n) for n in HEAD_LAYERS)
-        return _HeadFunction.apply(images_representation, questions_representation, dtype, masks,
+        if target is not None and not isinstance(target, (tuple, list)):
+            target = target.float()
+        logits, loss = _HeadFunction.apply(images_representation, questions_representation, dtype, masks, target,
                                    a.weight_g, a.weight_v, a.bias, s.weight_g, s.weight_v, i.weight_g, i.weight_v,
                                    i.bias, qq.weight_g, qq.weight_v, qq.bias, l.weight_g, l.weight_v, l.bias,
                                    f.weight_g, f.weight_v)
+        return logits if target is None else (logits, loss)
 
 
 VQAModel = VQA   # the name BASELINE.json's north_star uses

@@ -99,6 +99,12 @@ int vqa_bn_finalize(void* stream, const float* part, int rows, int C, double cou
 /* eval-mode BatchNorm2d: scale / shift from the running statistics. */
 int vqa_bn_eval_coeffs(void* stream, int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift);
+/* The same for all n (<= 16) layers of the encoder in one launch (inference, cnn.py:23-40 under model.eval()): gamma ..
+ * bias are HOST arrays of n device pointers (bias[i] = the conv's bias, may be NULL), C a host array of n channel counts;
+ * coef [n][3][ldc] f32 receives scale, shift and the bias of the folded conv, bias * scale + shift. */
+int vqa_bn_eval_coeffs_all(void* stream, int n, const void* const* gamma, const void* const* beta,
+                           const void* const* running_mean, const void* const* running_var, const void* const* bias,
+                           const int* C, float eps, float* coef, int ldc);
 /* BatchNorm apply + nn.ReLU + nn.MaxPool2d(2,2) / nn.AvgPool2d(2,2) (cnn.py:23-41): pool 0 none, 1 max, 2 avg. */
 int vqa_bn_act_pool_fwd(void* stream, int dtype, const void* y, void* a, const float* scale, const float* shift,
                         int B, int H, int W, int C, int pool);

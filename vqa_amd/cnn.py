@@ -370,15 +370,15 @@ def _eval_forward(x, first, params, buffers, padding, pool_mode, dtype):
     dev = x.device
     cinp = [CIN0_PAD] + list(CHANNELS[1:10])
     coef = torch.empty(10, 3, 256, device=dev, dtype=torch.float32)          # scale, shift, folded bias per layer
-    for li in range(10):
-        w, bias, gamma, beta = params[4 * li: 4 * li + 4]
-        c = w.shape[0]
-        L.call('vqa_bn_eval_coeffs', c, gamma, beta, buffers[2 * li], buffers[2 * li + 1], BN_EPS, coef[li, 0],
-               coef[li, 1])
-    coef[:, 2] = coef[:, 1]
-    for li in range(10):
-        c = params[4 * li].shape[0]
-        coef[li, 2, :c].addcmul_(params[4 * li + 1], coef[li, 0, :c])        # b' = shift + bias * scale
+    ct = L.ctypes
+    ptrs = lambda ts: (ct.c_void_p * 10)(*[t.data_ptr() for t in ts])
+    L.check(L.lib().vqa_bn_eval_coeffs_all(L.stream(), 10, ptrs([params[4 * li + 2] for li in range(10)]),
+                                           ptrs([params[4 * li + 3] for li in range(10)]),
+                                           ptrs([buffers[2 * li] for li in range(10)]),
+                                           ptrs([buffers[2 * li + 1] for li in range(10)]),
+                                           ptrs([params[4 * li + 1] for li in range(10)]),
+                                           (ct.c_int * 10)(*[params[4 * li].shape[0] for li in range(10)]),
+                                           ct.c_float(BN_EPS), L.ptr(coef), 256), 'vqa_bn_eval_coeffs_all')
     jobs = [(params[4 * li], cinp[li], False) for li in range(10) if not (first and li == 0)]
     scales = [coef[li, 0] for li in range(10) if not (first and li == 0)]
     slabs = ([None] if first else []) + pack_all(jobs, dtype, scales)

@@ -80,6 +80,31 @@ __global__ void bn_eval_coeffs(int C, const float* gamma, const float* beta, con
     shift[c] = beta[c] - running_mean[c] * sc;
 }
 
+// All layers of the encoder in one launch (inference): scale, shift and the bias the folded conv adds,
+// b' = conv_bias * scale + shift (W' = W * scale is folded at packing time: conv + BatchNorm + ReLU = one kernel).
+constexpr int BN_MAX_LAYERS = 16;
+struct EvalJobs {
+    const float* gamma[BN_MAX_LAYERS];
+    const float* beta[BN_MAX_LAYERS];
+    const float* rm[BN_MAX_LAYERS];
+    const float* rv[BN_MAX_LAYERS];
+    const float* bias[BN_MAX_LAYERS];
+    int C[BN_MAX_LAYERS];
+    float* coef;            // [n][3][ldc]: scale, shift, folded bias
+    int ldc;
+    float eps;
+};
+__global__ void bn_eval_coeffs_all(EvalJobs j) {
+    const int li = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= j.C[li]) return;
+    const float sc = j.gamma[li][c] / sqrtf(j.rv[li][c] + j.eps);
+    const float sh = j.beta[li][c] - j.rm[li][c] * sc;
+    float* o = j.coef + (long)li * 3 * j.ldc;
+    o[c] = sc;
+    o[j.ldc + c] = sh;
+    o[2 * j.ldc + c] = fmaf(j.bias[li] ? j.bias[li][c] : 0.f, sc, sh);
+}
+
 // ---- work distribution of the streaming kernels.  An item = one OUTPUT pixel x one 16-byte channel vector; item i
 // lives at element offset i*N of an un-pooled tensor.  Workgroup b owns the contiguous items [b*CH, (b+1)*CH),
 // CH = 256*U*passes: `passes` rounds of U independent items per thread (thread t takes base + u*256 + t), all loads of
@@ -402,6 +427,28 @@ extern "C" int vqa_bn_eval_coeffs(void* stream, int C, const float* gamma, const
                                   const float* running_var, float eps, float* scale, float* shift) {
     hipLaunchKernelGGL(bn_eval_coeffs, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), C, gamma,
                        beta, running_mean, running_var, eps, scale, shift);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+// n (<= 16) layers at once; gamma .. bias are HOST arrays of n device pointers (bias[i] may be NULL), C a host array of
+// n channel counts (<= ldc); coef [n][3][ldc] f32 receives scale, shift and the folded bias bias*scale + shift.
+extern "C" int vqa_bn_eval_coeffs_all(void* stream, int n, const void* const* gamma, const void* const* beta,
+                                      const void* const* running_mean, const void* const* running_var,
+                                      const void* const* bias, const int* C, float eps, float* coef, int ldc) {
+    if (n < 1 || n > BN_MAX_LAYERS || !gamma || !beta || !running_mean || !running_var || !bias || !C || !coef)
+        return VQA_ERR_ARG;
+    EvalJobs j{};
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (C[i] < 1 || C[i] > ldc) return VQA_ERR_ARG;
+        j.gamma[i] = static_cast<const float*>(gamma[i]); j.beta[i] = static_cast<const float*>(beta[i]);
+        j.rm[i] = static_cast<const float*>(running_mean[i]); j.rv[i] = static_cast<const float*>(running_var[i]);
+        j.bias[i] = static_cast<const float*>(bias[i]); j.C[i] = C[i];
+        if (C[i] > cmax) cmax = C[i];
+    }
+    j.coef = coef; j.ldc = ldc; j.eps = eps;
+    hipLaunchKernelGGL(bn_eval_coeffs_all, dim3((cmax + 255) / 256, n), dim3(256), 0, static_cast<hipStream_t>(stream), j);
     CHECK_LAUNCH();
     return VQA_OK;
 }

@@ -17,9 +17,11 @@ for sub, ctr in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != ctr: continue
         k = r['Kernel_Name']
-        fam = ('conv3x3_igemm' if 'conv3x3_igemm' in k else 'conv3x3_wgrad' if 'conv3x3_wgradI' in k else
-               'bn_bwd' if 'bn_bwd' in k and 'finalize' not in k else 'bn_act_pool_fwd' if 'bn_act_pool' in k else
-               'conv3x3_first_fwd' if 'first_fwd' in k else None)
+        fam = ('conv3x3_igemm_p' if 'conv3x3_igemm_p' in k else 'conv3x3_igemm_tile' if 'conv3x3_igemm_tile' in k else
+               'conv3x3_wgrad' if 'conv3x3_wgradI' in k else
+               'bn_bwd' if 'bn_bwd' in k and 'finalize' not in k else
+               'bn_act_pool_fwd' if ('bn_act_pool' in k or 'bn_pool_rows_fwd' in k) else
+               'conv3x3_first_fwd' if 'first_fwd' in k else 'conv3x3_first_wgrad' if 'first_wgrad' in k else None)
         if fam is None: continue
         res[fam][ctr] += float(r['Counter_Value'])
         if ctr == 'FETCH_SIZE': res[fam]['launches'] += 1

@@ -121,7 +121,7 @@ int vqa_bn_bwd_finalize(void* stream, const float* part, int rows, int C, double
 
 /* MFMA GEMM with fused epilogue.  trans = 0: C[M,N] = A[M,K] * B[N,K]^T (nn.Linear forward, input gradients with a
  * pre-transposed weight).  trans = 1: C[M,N] = A[K,M]^T * B[K,N] (weight gradients).  Epilogue: + bias[n],
- * + rowadd[m / rowadd_group][n], ReLU (act = 1), C += (accumulate = 1), optional bf16 copy C2.
+ * + rowadd[m / rowadd_group][n], activation (act = 1 ReLU, 3 SELU), C += (accumulate = 1), optional bf16 copy C2.
  * splits > 1: split-K over grid.z with raw partial sums in splitk_ws [splits][M][N] f32, summed in slice order. */
 int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
              void* C, int ldc, int c_dtype, const float* bias, const float* rowadd, int rowadd_group, int act,
@@ -176,8 +176,10 @@ int vqa_embed_bwd(void* stream, const long* q, const float* dx, int B, int T, in
  * included); save = [B][4H] (r, z, n, W_hn h + b_hn) for the backward.  H % 4 == 0 (16-byte accesses). */
 int vqa_gru_gate_fwd(void* stream, int dtype, const float* gi, const float* gh, const float* hprev, int B, int H,
                      float* hnew, void* hnew_t, float* save);
+/* dh_add (may be NULL): added to dhprev - the gradient a stacked layer above (nn.GRU num_layers > 1, gru.py:51) sends
+ * into h_{t-1} through its input projection. */
 int vqa_gru_gate_bwd(void* stream, int dtype, const float* dh, const float* save, const float* hprev, int B, int H,
-                     void* dgi, void* dgh, float* dhprev);
+                     void* dgi, void* dgh, float* dhprev, const float* dh_add);
 
 /* The recurrence of nn.GRU (gru.py:104) in its per-step form, all T steps issued by one call (the step is host-bound:
  * one binding call instead of 2 T): step t = vqa_gemm(h_t[t] x W_hh^T + b_hh -> gh) then vqa_gru_gate_fwd.  gi
@@ -187,10 +189,11 @@ int vqa_gru_fwd_steps(void* stream, int dtype, const float* gi, const void* w_hh
                       float* h_f, void* h_t, float* save, float* gh, float* splitk_ws, int splits, int B, int T, int H);
 /* BPTT of the same: step t = vqa_gru_gate_bwd then dh_{t-1} += dgh_t x W_hh (vqa_gemm, accumulate).  w_hh_t T
  * [H][ldw] (W_hh^T, 3H contiguous), outputs dgi / dgh T [T][B][3H], dh_ws [2][B][H] f32 scratch, splitk_ws
- * [splits][B][H] f32. */
+ * [splits][B][H] f32.  dh_seq (NULL for the top layer): f32 [T][B][H], the gradient a stacked layer above sends into
+ * every step's output; dh_last must already include dh_seq[T-1]. */
 int vqa_gru_bwd_steps(void* stream, int dtype, const float* dh_last, const float* save, const float* h_f,
                       const void* w_hh_t, int ldw, void* dgi, void* dgh, float* dh_ws, float* splitk_ws, int splits,
-                      int B, int T, int H);
+                      int B, int T, int H, const float* dh_seq);
 
 /* The whole nn.GRU recurrence (gru.py:104) in ONE persistent launch: each workgroup keeps its 48 x H slice of W_hh
  * (bf16) in LDS for all T steps, gates fused in registers, one device-wide barrier per step.  The grid is sized to be
@@ -213,15 +216,20 @@ int vqa_gru_bwd_persistent(void* stream, const void* wt, int ldw, const float* h
 int vqa_attn_fwd(void* stream, int dtype, const void* a, const void* ws, const float* v, int B, int K, int H, int D,
                  float* p, float* vhat, void* vhat_t);
 int vqa_attn_bwd(void* stream, int dtype, const void* a, const void* ws, const float* v, const float* p,
-                 const float* dvhat, int B, int K, int H, int D, float* dv, void* dpre, float* dws_part);
+                 const float* dvhat, int B, int K, int H, int D, float* dv, void* dpre, float* dws_part, int act);
 /* out[b] = sum_k x[b*K + k] (gradient of the question term broadcast over regions, vqa_model.py:83-87). */
 int vqa_group_sum(void* stream, int dtype, const void* x, int B, int K, int H, float* out, void* out_t);
-/* vqa_model.py:99-101: fv * fq (* dropout mask), and its backward through both ReLUs. */
-int vqa_hadamard_fwd(void* stream, int dtype, const float* fv, const float* fq, const float* mask, long n, void* out);
+/* vqa_model.py:99-101: fv * fq (* dropout mask), and its backward through both activations.
+ * act (here and in vqa_attn_bwd / vqa_gemm): 1 = nn.ReLU, 3 = nn.SELU (vqa_model.py:54; the backward forms the
+ * derivative from the activation's saved output).  mask / add: out = x * mask + add, either may be NULL - nn.Dropout
+ * is mask = keep / (1-p); nn.AlphaDropout (vqa_model.py:55, selu branch) is mask = a * keep, add = a * alpha' *
+ * (1 - keep) + b with torch's a, b, alpha' for p = 0.5. */
+int vqa_hadamard_fwd(void* stream, int dtype, const float* fv, const float* fq, const float* mask, long n, void* out,
+                     const float* add);
 int vqa_hadamard_bwd(void* stream, int dtype, const float* dm0, const float* fv, const float* fq, const float* mask,
-                     long n, void* dpv, void* dpq);
-int vqa_relu_bwd(void* stream, int dtype, const float* g, const float* act, const float* mask, long n, void* out);
-int vqa_mask_mul(void* stream, int dtype, const float* x, const float* mask, long n, void* out);
+                     long n, void* dpv, void* dpq, int act);
+int vqa_relu_bwd(void* stream, int dtype, const float* g, const float* y, const float* mask, long n, void* out, int act);
+int vqa_mask_mul(void* stream, int dtype, const float* x, const float* mask, long n, void* out, const float* add);
 
 /* ---------------------------------------------------------------- loss, accuracy, optimizer */
 

@@ -133,54 +133,88 @@ def cnn_forward(sd, x, padding=2, pooling='max', training=True, new_stats=None, 
 
 
 def gru_forward(sd, q, inter=None):
-    """reference gru.py:101-106: embedding gather, 1-layer GRU (gate rows [r;z;n]), h0 = 0, returns h_T."""
-    emb = sd['gru.word_embedding.weight'][q]                          # [B,T,E]
-    w_ih, w_hh = sd['gru.encoder.weight_ih_l0'], sd['gru.encoder.weight_hh_l0']
-    b_ih, b_hh = sd['gru.encoder.bias_ih_l0'], sd['gru.encoder.bias_hh_l0']
-    H = w_hh.shape[1]
-    h = torch.zeros(q.shape[0], H, dtype=emb.dtype)
-    for t in range(q.shape[1]):
-        gi = emb[:, t] @ w_ih.t() + b_ih
-        gh = h @ w_hh.t() + b_hh
-        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
-        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
-        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
-        h = (1 - z) * n + z * h
+    """reference gru.py:101-106: embedding gather, nn.GRU (gate rows [r;z;n], h0 = 0, layer k > 0 fed by the output
+    sequence of layer k-1, no inter-layer dropout: gru.py:51-52), returns the top layer's h_T."""
+    seq = sd['gru.word_embedding.weight'][q]                          # [B,T,E]
+    layer = 0
+    while f'gru.encoder.weight_ih_l{layer}' in sd:
+        w_ih, w_hh = sd[f'gru.encoder.weight_ih_l{layer}'], sd[f'gru.encoder.weight_hh_l{layer}']
+        b_ih, b_hh = sd[f'gru.encoder.bias_ih_l{layer}'], sd[f'gru.encoder.bias_hh_l{layer}']
+        H = w_hh.shape[1]
+        h = torch.zeros(q.shape[0], H, dtype=seq.dtype)
+        outs = []
+        for t in range(q.shape[1]):
+            gi = seq[:, t] @ w_ih.t() + b_ih
+            gh = h @ w_hh.t() + b_hh
+            r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+            z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+            h = (1 - z) * n + z * h
+            outs.append(h)
+        seq = torch.stack(outs, dim=1)
+        layer += 1
     return h
 
 
-def head_forward(sd, v, q, inter=None, masks=None):
+SELU_SCALE, SELU_ALPHA = 1.0507009873554805, 1.6732632423543772
+
+
+def selu(x):
+    """nn.SELU (reference vqa_model.py:54, the non-'relu' branch): scale * (max(0,x) + min(0, alpha * (e^x - 1)))."""
+    return SELU_SCALE * (torch.clamp(x, min=0) + torch.clamp(SELU_ALPHA * torch.expm1(x), max=0))
+
+
+def alpha_dropout_noise(keep, p=0.5):
+    """nn.AlphaDropout (reference vqa_model.py:55: nn.AlphaDropout(), p = 0.5) from a 0/1 keep tensor, as ATen forms it:
+    alpha' = scale * alpha, a = ((alpha'^2 p + 1)(1 - p))^-1/2, out = x * (a keep) + ((keep - 1) alpha' a + alpha' a p).
+    Returns the (mask, add) pair head_forward takes for a dropout site."""
+    ap = SELU_SCALE * SELU_ALPHA
+    a = 1.0 / ((ap * ap * p + 1.0) * (1.0 - p)) ** 0.5
+    keep = keep.to(torch.float32)
+    return keep * a, (keep - 1.0) * (ap * a) + ap * a * p
+
+
+def _drop(x, site):
+    if site is None:
+        return x
+    if isinstance(site, (tuple, list)):
+        mask, add = site
+        return x * mask + add
+    return x * site
+
+
+def head_forward(sd, v, q, inter=None, masks=None, activation='relu'):
     """reference vqa_model.py:83-103.  v [B,k,D], q [B,H] -> logits [B,C].
-    masks = (noise1, noise2): the two nn.Dropout noise tensors [B,H] (keep / (1-p), vqa_model.py:55) multiplied in at
-    :101 and :103; None = dropout p=0 / eval (identity)."""
+    masks = (site1, site2): the two dropout sites of :101 and :103 - an nn.Dropout noise tensor [B,H] (keep / (1-p),
+    vqa_model.py:55), an nn.AlphaDropout (mask, add) pair (alpha_dropout_noise), or None = identity (p=0 / eval).
+    activation: 'relu' -> nn.ReLU, anything else -> nn.SELU (vqa_model.py:54)."""
+    act = torch.relu if activation == 'relu' else selu
     W = {n: weight_norm_w(sd[f'{n}.weight_g'], sd[f'{n}.weight_v']) for n in HEAD_LAYERS}
     B, k, _ = v.shape
     concat = torch.cat((v, q[:, None, :].expand(B, k, q.shape[1])), dim=2)
-    a = torch.relu(concat @ W['linear_inside_relu_attention'].t() + sd['linear_inside_relu_attention.bias'])
+    a = act(concat @ W['linear_inside_relu_attention'].t() + sd['linear_inside_relu_attention.bias'])
     s = a @ W['linear_after_relu_attention'].t()                      # [B,k,1]
     p = torch.softmax(s, dim=1)
     vhat = torch.sum(p * v, dim=1)
-    fv = torch.relu(vhat @ W['linear_inside_relu_image'].t() + sd['linear_inside_relu_image.bias'])
-    fq = torch.relu(q @ W['linear_inside_relu_question'].t() + sd['linear_inside_relu_question.bias'])
-    had = fv * fq
-    if masks is not None and masks[0] is not None:
-        had = had * masks[0]
-    m = torch.relu(had @ W['linear_inside_relu_last'].t() + sd['linear_inside_relu_last.bias'])
-    if masks is not None and masks[1] is not None:
-        m = m * masks[1]
+    fv = act(vhat @ W['linear_inside_relu_image'].t() + sd['linear_inside_relu_image.bias'])
+    fq = act(q @ W['linear_inside_relu_question'].t() + sd['linear_inside_relu_question.bias'])
+    had = _drop(fv * fq, None if masks is None else masks[0])
+    m = act(had @ W['linear_inside_relu_last'].t() + sd['linear_inside_relu_last.bias'])
+    m = _drop(m, None if masks is None else masks[1])
     if inter is not None:
         inter['att_p'] = p[:, :, 0]
     return m @ W['fc'].t()
 
 
-def forward(sd, images, questions, padding=2, pooling='max', training=True, new_stats=None, inter=None, masks=None):
+def forward(sd, images, questions, padding=2, pooling='max', training=True, new_stats=None, inter=None, masks=None,
+            activation='relu'):
     """reference vqa_model.py:77-103."""
     dt = sd['cnn.convolutions.0.weight'].dtype      # fp32; tests may pass an fp64 copy for a truth run
     v = cnn_forward(sd, images.to(dt), padding, pooling, training, new_stats, inter)
     q = gru_forward(sd, questions, inter)
     if inter is not None:
         inter['cnn_out'], inter['gru_out'] = v, q
-    return head_forward(sd, v, q, inter, masks)
+    return head_forward(sd, v, q, inter, masks, activation)
 
 
 def bce_sum(logits, target):
@@ -205,11 +239,11 @@ def dropout_noise(keep, p):
     return keep.to(torch.float32).div_(1.0 - p)
 
 
-def train_step_grads(sd, images, questions, target, padding=2, pooling='max', masks=None):
+def train_step_grads(sd, images, questions, target, padding=2, pooling='max', masks=None, activation='relu'):
     """One fwd+bwd (reference vqa_model.py:254-256).  Returns (loss, logits, grads, new_running_stats)."""
     p = {k: (v.detach().clone().requires_grad_(True) if is_param(k) else v) for k, v in sd.items()}
     new_stats = {}
-    logits = forward(p, images, questions, padding, pooling, True, new_stats, None, masks)
+    logits = forward(p, images, questions, padding, pooling, True, new_stats, None, masks, activation)
     loss = bce_sum(logits, target)
     names = [k for k in p if is_param(k)]
     gs = torch.autograd.grad(loss, [p[k] for k in names])

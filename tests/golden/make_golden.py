@@ -40,7 +40,14 @@ CONFIGS = [
     # the authors' final dropout (vqa_model.py:407-416): the two nn.Dropout keep-masks of the step are captured by a
     # forward hook on the reference's own module and stored, so the HIP path can replay them
     ('h1024_p2_max_b32_drop', 1024, 3129, 2, 'max', 32, 224, 14),
+    # round 2: the reference's other activation branch (vqa_model.py:54-55: nn.SELU + nn.AlphaDropout(), p = 0.5; the
+    # keep-masks of the two AlphaDropout sites are recovered from the module's input / output and stored)
+    ('h64_p2_max_selu', 64, 50, 2, 'max', 4, 224, 9),
+    # and a stacked question encoder (gru.py:51 num_layers = 2)
+    ('h64_p2_max_l2', 64, 50, 2, 'max', 4, 224, 9),
 ]
+ACTIVATION = {'h64_p2_max_selu': 'selu'}
+N_LAYERS = {'h64_p2_max_l2': 2}
 DROPOUT = {'h1024_p2_max_b32_drop': 0.0381}
 MULTI_STEP = {'h1024_p2_max_b32': 3}
 SEED_W, SEED_X = 42, 1234
@@ -102,10 +109,12 @@ def run_config(vqa_model, name, hidden, classes, padding, pooling, batch, size, 
     qpath = fixture_files(tmp)
     lpath = os.path.join(tmp, f'label2ans_{classes}.pkl')
     pickle.dump([f'ans{i}' for i in range(classes)], open(lpath, 'wb'))
-    model = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': hidden, 'n_layers': 1,
-                           'train_question_path': qpath}, lpath, 256, padding, DROPOUT.get(name, 0.0), pooling, 'relu')
+    activation, n_layers = ACTIVATION.get(name, 'relu'), N_LAYERS.get(name, 1)
+    model = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': hidden, 'n_layers': n_layers,
+                           'train_question_path': qpath}, lpath, 256, padding, DROPOUT.get(name, 0.0), pooling,
+                          activation)
     vocab = len(model.gru.word_idx_mappings)
-    sd = synth.state_dict(SEED_W, hidden, classes, vocab)
+    sd = synth.state_dict(SEED_W, hidden, classes, vocab, n_layers=n_layers)
     model.load_state_dict(sd, strict=True)
     img = synth.images(SEED_X, batch, size)                  # fp16 like dataset.py:98
     q = synth.questions(SEED_X, batch, tokens, vocab)
@@ -151,13 +160,25 @@ def run_config(vqa_model, name, hidden, classes, padding, pooling, batch, size, 
             keeps.append(((outp != 0) | (inp[0] == 0)).numpy())
         handle = model.dropout.register_forward_hook(hook)
         torch.manual_seed(777)
+    if activation != 'relu':
+        # nn.AlphaDropout(p=0.5): a dropped element leaves the module as the constant a * (-alpha') + b whatever its
+        # input was; a kept one as a * x + b.  keep = "output is not that constant" (an input equal to -alpha' itself
+        # would be indistinguishable and harmless: same output either way, gradient factor differs only there)
+        ap, pp = 1.7580993408473766, 0.5
+        a_ = 1.0 / ((ap * ap * pp + 1.0) * (1.0 - pp)) ** 0.5
+        dropped_value = a_ * (-ap) + ap * a_ * pp
+
+        def hook(_m, inp, outp):
+            keeps.append((torch.abs(outp - dropped_value) > 1e-6).numpy())
+        handle = model.dropout.register_forward_hook(hook)
+        torch.manual_seed(777)
     logits = model(img.float(), q)
     loss = crit(logits, tgt)
     loss.backward()
-    if name in DROPOUT:
+    if name in DROPOUT or activation != 'relu':
         handle.remove()
         assert len(keeps) == 2
-        out['dropout_p'] = np.float64(DROPOUT[name])
+        out['dropout_p'] = np.float64(DROPOUT[name] if name in DROPOUT else 0.5)
         out['keep1'], out['keep2'] = np.packbits(keeps[0]), np.packbits(keeps[1])
         print('  dropout: dropped', int((~keeps[0]).sum()), int((~keeps[1]).sum()), 'of', keeps[0].size)
     out['logits'], out['loss'] = logits.detach().numpy(), np.float64(loss)

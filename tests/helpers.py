@@ -23,6 +23,14 @@ DROPOUT_CONFIGS = {
 }
 
 
+# the reference's other branches: name -> (config, activation, n_layers).  'selu' = nn.SELU + nn.AlphaDropout(p=0.5)
+# (vqa_model.py:54-55; the recorded keep-masks of the two sites are in the golden file); n_layers = 2 = stacked nn.GRU
+VARIANT_CONFIGS = {
+    'h64_p2_max_selu': ((64, 50, 2, 'max', 4, 224, 9), 'selu', 1),
+    'h64_p2_max_l2': ((64, 50, 2, 'max', 4, 224, 9), 'relu', 2),
+}
+
+
 def sample_idx(n):
     if n <= SAMPLE:
         return np.arange(n)
@@ -30,12 +38,16 @@ def sample_idx(n):
 
 
 def load_case(name):
-    hidden, classes, padding, pooling, batch, size, tokens = (CONFIGS.get(name) or DROPOUT_CONFIGS[name])
+    activation, n_layers = 'relu', 1
+    if name in VARIANT_CONFIGS:
+        (hidden, classes, padding, pooling, batch, size, tokens), activation, n_layers = VARIANT_CONFIGS[name]
+    else:
+        hidden, classes, padding, pooling, batch, size, tokens = (CONFIGS.get(name) or DROPOUT_CONFIGS[name])
     g = np.load(os.path.join(GOLDEN_DIR, f'{name}.npz'))
     vocab = int(g['vocab'])
     case = dict(hidden=hidden, classes=classes, padding=padding, pooling=pooling, batch=batch, size=size,
-                tokens=tokens, vocab=vocab, golden=g,
-                sd=synth.state_dict(SEED_W, hidden, classes, vocab),
+                tokens=tokens, vocab=vocab, golden=g, activation=activation, n_layers=n_layers,
+                sd=synth.state_dict(SEED_W, hidden, classes, vocab, n_layers=n_layers),
                 images=synth.images(SEED_X, batch, size),
                 questions=synth.questions(SEED_X, batch, tokens, vocab),
                 targets=synth.targets(SEED_X, batch, classes))
@@ -43,7 +55,11 @@ def load_case(name):
         p = float(g['dropout_p'])
         keep = [torch.from_numpy(np.unpackbits(g[k])[:batch * hidden].reshape(batch, hidden).astype(bool))
                 for k in ('keep1', 'keep2')]
-        case.update(dropout=p, keep=keep, noise=[k.to(torch.float32).div_(1.0 - p) for k in keep])
+        if activation == 'relu':
+            case.update(dropout=p, keep=keep, noise=[k.to(torch.float32).div_(1.0 - p) for k in keep])
+        else:       # nn.AlphaDropout: every site is a (mask, add) pair
+            from oracle import vqa_oracle as O
+            case.update(keep=keep, noise=[O.alpha_dropout_noise(k, p) for k in keep])
     return case
 
 
@@ -74,9 +90,9 @@ def build_model(case, tmp, precision):
     """The HIP-backed VQA for a golden case, loaded with the case's synthetic state dict."""
     import vqa_model
     qpath, lpath = fixture_files(tmp, case['classes'])
-    m = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': case['hidden'], 'n_layers': 1,
+    m = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': case['hidden'], 'n_layers': case.get('n_layers', 1),
                        'train_question_path': qpath}, lpath, 256, case['padding'], case.get('dropout', 0.0),
-                      case['pooling'], 'relu', precision=precision)
+                      case['pooling'], case.get('activation', 'relu'), precision=precision)
     assert len(m.gru.word_idx_mappings) == case['vocab']
     m.load_state_dict(case['sd'], strict=True)
     return m

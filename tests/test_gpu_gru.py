@@ -5,31 +5,35 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _mk(H, V, tmp_path, prec):
+def _mk(H, V, tmp_path, prec, layers=1):
     from tests.helpers import fixture_files
     from vqa_amd import synth
     import gru
     qpath, _ = fixture_files(tmp_path, 5)
-    g = gru.GRU(300, H, 1, qpath, precision=prec)
-    sd = {k[4:]: v for k, v in synth.state_dict(3, H, 5, 82).items() if k.startswith('gru.')}
+    g = gru.GRU(300, H, layers, qpath, precision=prec)
+    sd = {k[4:]: v for k, v in synth.state_dict(3, H, 5, 82, n_layers=layers).items() if k.startswith('gru.')}
     g.load_state_dict(sd)
     return g.cuda(), {'gru.' + k: v for k, v in sd.items()}
 
 
-@pytest.mark.parametrize('prec,H,B,T,tol,persistent',
-                         [('fp32', 64, 5, 7, 2e-5, False), ('fp32', 256, 3, 14, 2e-5, False),
-                          ('bf16', 256, 70, 14, 3e-2, False), ('bf16', 512, 130, 9, 3e-2, False),
-                          ('bf16', 256, 70, 14, 3e-2, True), ('bf16', 512, 130, 9, 3e-2, True),
+@pytest.mark.parametrize('prec,H,B,T,tol,persistent,layers',
+                         [('fp32', 64, 5, 7, 2e-5, False, 1), ('fp32', 256, 3, 14, 2e-5, False, 1),
+                          ('bf16', 256, 70, 14, 3e-2, False, 1), ('bf16', 512, 130, 9, 3e-2, False, 1),
+                          ('bf16', 256, 70, 14, 3e-2, True, 1), ('bf16', 512, 130, 9, 3e-2, True, 1),
                           # the benchmark's shape (configs[1]) on both launch structures, and configs[4]'s large hidden
                           # size (the persistent kernel's W_hh slice no longer fits LDS there: it must fall back)
-                          ('bf16', 1024, 256, 14, 3e-2, False), ('bf16', 1024, 256, 14, 3e-2, True),
-                          ('bf16', 2048, 64, 30, 3e-2, True)])
-def test_gru_vs_oracle(prec, H, B, T, tol, persistent, tmp_path, monkeypatch):
+                          ('bf16', 1024, 256, 14, 3e-2, False, 1), ('bf16', 1024, 256, 14, 3e-2, True, 1),
+                          ('bf16', 2048, 64, 30, 3e-2, True, 1),
+                          # stacked nn.GRU (gru.py:51 num_layers > 1): every layer's BPTT takes the gradient of the
+                          # layer above at every step (vqa_gru_bwd_steps dh_seq)
+                          ('fp32', 64, 5, 7, 2e-5, False, 2), ('fp32', 256, 3, 14, 3e-5, False, 3),
+                          ('bf16', 256, 70, 14, 4e-2, False, 2), ('bf16', 1024, 64, 14, 4e-2, True, 2)])
+def test_gru_vs_oracle(prec, H, B, T, tol, persistent, layers, tmp_path, monkeypatch):
     from oracle import vqa_oracle as O
     from vqa_amd import synth
     import vqa_amd.gru as G
     monkeypatch.setattr(G, 'USE_PERSISTENT', persistent)
-    g, sd = _mk(H, 82, tmp_path, prec)
+    g, sd = _mk(H, 82, tmp_path, prec, layers)
     q = synth.questions(5, B, T, 82)
     dh = torch.randn(B, H)
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}

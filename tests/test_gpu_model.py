@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import CONFIGS, build_model, load_case, rel_err, sample_idx
+from tests.helpers import CONFIGS, VARIANT_CONFIGS, build_model, load_case, rel_err, sample_idx
 
 pytestmark = pytest.mark.gpu
 
@@ -55,6 +55,57 @@ def test_fp32_model_vs_golden(name, tmp_path):
         tol = 3e-2 if grp == 'cnn' else (2e-3 if grp == 'weight_g' else 5e-4)
         assert e < tol, (k, e)
     print(f'\n[{name}] logits {rel_err(logits.detach().cpu(), g["logits"]):.2e} worst grads {worst}')
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('name', list(VARIANT_CONFIGS))
+def test_variants_vs_golden(name, prec, tmp_path):
+    """activation='selu' (nn.SELU + nn.AlphaDropout(0.5), vqa_model.py:54-55; the reference's recorded keep-masks
+    replayed through forward(dropout_noise=...)) and n_layers=2 (stacked nn.GRU, gru.py:51) against the golden vectors
+    of the imported reference.  fp32: the bounds of test_fp32_model_vs_golden.  bf16: outputs only - at B=4 the bf16
+    image encoder's training-mode output moves every gradient behind it; the bf16 gradients of these two
+    branches are pinned where that noise is absent: the head on given encoder outputs
+    (test_gpu_train_parity.py::test_head_fwd_bwd_vs_oracle, selu cases) and the stacked encoder alone
+    (test_gpu_gru.py::test_gru_vs_oracle, layers > 1)."""
+    import vqa_model
+    from oracle import vqa_oracle as O
+    c = load_case(name)
+    g = c['golden']
+    m = build_model(c, tmp_path, prec).cuda()
+    img, q, t = c['images'].cuda(), c['questions'].cuda(), c['targets'].cuda()
+    tol_out = 1e-4 if prec == 'fp32' else 3e-2
+    m.eval()
+    with torch.no_grad():
+        lo = m(img, q)
+    assert rel_err(lo.cpu(), g['eval_logits']) < tol_out
+    m.train()
+    noise = c.get('noise')
+    if noise is not None:
+        noise = [tuple(x.cuda() for x in st) if isinstance(st, (tuple, list)) else st.cuda() for st in noise]
+    logits = m(img, q, dropout_noise=noise)
+    loss = vqa_model.SoftScoreBCELoss()(logits, t)
+    loss.backward()
+    assert rel_err(logits.detach().cpu(), g['logits']) < tol_out
+    assert abs(float(loss.detach()) - float(g['loss'])) < (3e-4 if prec == 'fp32' else 3e-2) * abs(float(g['loss']))
+    worst = {}
+    for k, p in m.named_parameters():
+        flat = p.grad.detach().reshape(-1).cpu()
+        assert bool(torch.isfinite(flat).all()), k
+        if prec == 'bf16' or (k.startswith('cnn.') and k.endswith('.bias') and int(k.split('.')[2]) in O.CONV_IDX):
+            continue
+        e = rel_err(flat.numpy()[sample_idx(flat.numel())], g[f'gsamp/{k}'])
+        grp = 'cnn' if k.startswith('cnn.') else ('weight_g' if k.endswith('weight_g') else 'gru+head')
+        worst[grp] = max(worst.get(grp, 0.0), e)
+        tol = 3e-2 if grp == 'cnn' else (2e-3 if grp == 'weight_g' else 5e-4)
+        assert e < tol, (k, e)
+    print(f'\n[{name} {prec}] logits {rel_err(logits.detach().cpu(), g["logits"]):.2e} worst grads {worst}')
+    if c['activation'] != 'relu':
+        # module-drawn AlphaDropout (no injected noise): training output differs from eval, p is 0.5 whatever `dropout`
+        with torch.no_grad():
+            a, b = m(img, q), m(img, q)
+        assert not torch.equal(a, b)
+        mk, ad = m._dropout_mask(4, img.device)
+        assert 0.3 < float((mk != 0).float().mean()) < 0.7 and ad is not None
 
 
 def test_eval32_soft_accuracy_identical(tmp_path):

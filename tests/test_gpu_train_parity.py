@@ -29,29 +29,42 @@ def _is_conv_bias(k):
 HEAD_BF16 = dict(logits=1.5e-2, dv=6e-2, dq=6e-2, att=1e-1, grad=6e-2, weight_g=2e-2)
 
 
-@pytest.mark.parametrize('K,H,B', [(25, 1024, 32), (144, 512, 24), (25, 512, 40), (144, 1024, 16)])
+@pytest.mark.parametrize('K,H,B,act', [(25, 1024, 32, 'relu'), (144, 512, 24, 'relu'), (25, 512, 40, 'relu'),
+                                       (144, 1024, 16, 'relu'),
+                                       # the reference's other branch (vqa_model.py:54-55): nn.SELU at the four
+                                       # activation sites, nn.AlphaDropout(p=0.5) noise at the two dropout sites
+                                       (25, 1024, 32, 'selu'), (144, 512, 24, 'selu')])
 @pytest.mark.parametrize('prec', ['bf16', 'fp32'])
-def test_head_fwd_bwd_vs_oracle(prec, K, H, B, tmp_path):
+def test_head_fwd_bwd_vs_oracle(prec, K, H, B, act, tmp_path):
     """_HeadFunction on GIVEN fp32 v [B,k,256], q [B,H]: logits, dv, dq and all 16 head parameter gradients against
     oracle.head_forward autograd (vqa_model.py:83-103) with the sum-BCE loss on top (:215)."""
     import vqa_model
     from oracle import vqa_oracle as O
     from vqa_amd import synth
     C = 3129
-    case = dict(hidden=H, classes=C, padding=2, pooling='max', vocab=82, sd=synth.state_dict(42, H, C, 82))
+    case = dict(hidden=H, classes=C, padding=2, pooling='max', vocab=82, sd=synth.state_dict(42, H, C, 82),
+                activation=act)
     m = build_model(case, tmp_path, prec).cuda().train()
+    noise = noise_dev = None
+    if act != 'relu':
+        noise = [O.alpha_dropout_noise(synth.randint(5, f'head.keep{i}', (B, H), 0, 2)) for i in (1, 2)]
+        noise_dev = [tuple(x.cuda() for x in st) for st in noise]
     v = torch.relu(synth.uniform(5, 'head.v', (B, K, 256), -0.6, 1.4))      # pooled post-ReLU features, some zeros
     q = synth.uniform(5, 'head.q', (B, H), -1.0, 1.0)                       # GRU hidden state range
     t = synth.targets(5, B, C)
     p = {k: (x.clone().requires_grad_(True) if O.is_param(k) else x) for k, x in case['sd'].items()
          if not k.startswith(('cnn.', 'gru.'))}
     vr, qr = v.clone().requires_grad_(True), q.clone().requires_grad_(True)
-    lo_ref = O.head_forward(p, vr, qr)
+    lo_ref = O.head_forward(p, vr, qr, masks=noise, activation=act)
     O.bce_sum(lo_ref, t).backward()
     vd, qd = v.cuda().requires_grad_(True), q.cuda().requires_grad_(True)
-    lo = m.head(vd, qd)
+    lo = m.head(vd, qd, dropout_noise=noise_dev)
     vqa_model.SoftScoreBCELoss()(lo, t.cuda()).backward()
     tol = HEAD_BF16 if prec == 'bf16' else dict(logits=2e-5, dv=2e-5, dq=2e-5, grad=5e-5, weight_g=2e-5)
+    if prec == 'bf16' and act != 'relu':
+        # SELU's derivative is formed from the bf16-stored activation over its whole negative half (ReLU's is a sign),
+        # and half the units are replaced by AlphaDropout's constant [measured att 8.6e-2 .. 9.8e-2]
+        tol = dict(tol, att=1.5e-1)
     errs = dict(logits=rel_err(lo.detach().cpu(), lo_ref.detach()), dv=rel_err(vd.grad.cpu(), vr.grad),
                 dq=rel_err(qd.grad.cpu(), qr.grad))
     for k, e in errs.items():
@@ -70,7 +83,7 @@ def test_head_fwd_bwd_vs_oracle(prec, K, H, B, tmp_path):
                                                              'linear_after_relu_attention'))) else 'grad'
         worst[grp] = max(worst.get(grp, 0.0), e)
         assert e < tol[grp], (k, e)
-    print(f'\n[head {prec} K={K} H={H} B={B}] ' + ' '.join(f'{k} {e:.2e}' for k, e in {**errs, **worst}.items()))
+    print(f'\n[head {prec} {act} K={K} H={H} B={B}] ' + ' '.join(f'{k} {e:.2e}' for k, e in {**errs, **worst}.items()))
 
 
 # ---- whole model against the B=32 golden.
@@ -201,11 +214,12 @@ def test_dropout_replayed_vs_golden(prec, tmp_path):
     own = m(c['images'].cuda(), c['questions'].cuda())                        # its own Bernoulli draws
     assert rel_err(own.detach().cpu(), c['golden']['logits']) > 10 * B32_TOL['fp32']['logits']
     # the module's own draws are inverted dropout: kept fraction ~ 1 - p, kept values scaled by 1 / (1 - p)
-    mask = m._dropout_mask(4096, torch.device('cuda'))
+    mask, add = m._dropout_mask(4096, torch.device('cuda'))
+    assert add is None                                                        # nn.Dropout: multiplicative only
     assert abs(float((mask > 0).float().mean()) - (1 - 0.0381)) < 5e-3
     assert float(mask.max()) == pytest.approx(1 / (1 - 0.0381), rel=1e-6)
     m.eval()
-    assert m._dropout_mask(4, torch.device('cuda')) is None
+    assert m._dropout_mask(4, torch.device('cuda')) == (None, None)
 
 
 @pytest.mark.parametrize('prec,tol_scalar,tol_update', [('fp32', 5e-3, 1e-2)])

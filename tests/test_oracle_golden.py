@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import vqa_oracle as O
-from tests.helpers import CONFIGS, load_case, rel_err, sample_idx
+from tests.helpers import CONFIGS, VARIANT_CONFIGS, load_case, rel_err, sample_idx
 
 TOL = 1e-5
 
@@ -178,5 +178,38 @@ def test_dropout_masks_replayed(monkeypatch):
         if k.startswith('cnn.convolutions') and k.endswith('.bias') and int(k.split('.')[2]) in O.CONV_IDX:
             continue
         tol = 1e-2 if k.startswith('cnn.') else (1e-3 if k.endswith('weight_g') else 2e-4)
+        flat = gr.reshape(-1)
+        assert rel_err(flat.numpy()[sample_idx(flat.numel())], g[f'gsamp/{k}']) < tol, k
+
+
+@pytest.mark.parametrize('name', list(VARIANT_CONFIGS))
+def test_oracle_variants_match_reference(name, monkeypatch):
+    """The reference's other branches, imported and run like the main cases (tests/golden/make_golden.py):
+    activation='selu' (vqa_model.py:54-55: nn.SELU at the four activation sites + nn.AlphaDropout(p=0.5) at the two
+    dropout sites, the recorded keep-masks replayed) and n_layers=2 (gru.py:51: stacked nn.GRU)."""
+    monkeypatch.setattr(O, 'REFERENCE_NORM', True)
+    c = load_case(name)
+    g = c['golden']
+    act = c['activation']
+    lo = O.forward(c['sd'], c['images'], c['questions'], c['padding'], c['pooling'], training=False, activation=act)
+    assert rel_err(lo, g['eval_logits']) < TOL
+    inter = {}
+    O.forward(c['sd'], c['images'], c['questions'], c['padding'], c['pooling'], True, None, inter, activation=act)
+    assert rel_err(inter['gru_out'], g['gru_out']) < TOL
+    loss, logits, grads, _ = O.train_step_grads(c['sd'], c['images'], c['questions'], c['targets'], c['padding'],
+                                                c['pooling'], masks=c.get('noise'), activation=act)
+    assert rel_err(logits, g['logits']) < TOL
+    assert abs(float(loss) - float(g['loss'])) < TOL * abs(float(g['loss']))
+    if act != 'relu':
+        for k in c['keep']:
+            assert 0.3 < float(k.float().mean()) < 0.7                  # p = 0.5 whatever `dropout` says
+        plain = O.train_step_grads(c['sd'], c['images'], c['questions'], c['targets'], c['padding'], c['pooling'],
+                                   activation=act)[1]
+        assert rel_err(plain, g['logits']) > 1e-2                       # the AlphaDropout noise matters
+    assert set(grads) == {k[len('gnorm/'):] for k in g.files if k.startswith('gnorm/')}
+    for k, gr in grads.items():
+        if k.startswith('cnn.convolutions') and k.endswith('.bias') and int(k.split('.')[2]) in O.CONV_IDX:
+            continue
+        tol = 3e-2 if k.startswith('cnn.') else (1e-3 if k.endswith('weight_g') else 2e-4)
         flat = gr.reshape(-1)
         assert rel_err(flat.numpy()[sample_idx(flat.numel())], g[f'gsamp/{k}']) < tol, k

@@ -55,6 +55,41 @@ template <> struct Mma<bf16> {
     }
 };
 
+// XCD-aware walk of a persistent grid over `total` work units (image-major tiles).  Workgroups are dealt to the 8
+// XCDs round-robin by linear id (x, x + 8, ... share one XCD and its 4 MiB L2; MI355X_MICROARCH.md, workgroup
+// dispatch), so with the old walk u = x, x + G, ... the G tiles in flight at any moment - spatial neighbours that
+// share their halo rows / columns - sat on 8 different L2s and every halo was fetched from the fabric once per
+// XCD (PMC: 1.4x the algorithmic input bytes on the single-chunk conv).  Here XCD k owns the contiguous eighth
+// [total*k/8, total*(k+1)/8) of the unit list and its G/8 workgroups walk it side by side: neighbours meet in one L2.
+// Placement is a speed matter only: any dispatch order gives the same results (the unit -> workgroup map is fixed).
+#ifndef VQA_XCD_WALK
+#define VQA_XCD_WALK 1
+#endif
+struct UnitWalk { int first, step, end; };
+__device__ __forceinline__ UnitWalk unit_walk(int x, int G, int total) {
+    if (VQA_XCD_WALK && (G & 7) == 0 && total >= G) {
+        const int k = x & 7;
+        return {(int)(((long)total * k) >> 3) + (x >> 3), G >> 3, (int)(((long)total * (k + 1)) >> 3)};
+    }
+    return {x, G, total};
+}
+
+// Head activations (reference vqa_model.py:54: nn.ReLU() if activation == 'relu' else nn.SELU()).  act codes of the
+// C-ABI: 0 none, 1 ReLU, 3 SELU (2 is the classifier's sigmoid-BCE epilogue).  The backward kernels take the
+// derivative from the saved OUTPUT y: ReLU 1[y > 0]; SELU scale for y > 0, else y + scale*alpha (= scale*alpha*e^x).
+#define VQA_ACT_RELU 1
+#define VQA_ACT_SELU 3
+__device__ __forceinline__ float selu_f(float x) {
+    return x > 0.f ? 1.0507009873554805f * x : 1.7580993408473766f * expm1f(x);
+}
+__device__ __forceinline__ float act_apply(float x, int act) {
+    return act == VQA_ACT_RELU ? fmaxf(x, 0.f) : (act == VQA_ACT_SELU ? selu_f(x) : x);
+}
+__device__ __forceinline__ float act_grad(float y, int act) {
+    if (act == VQA_ACT_SELU) return y > 0.f ? 1.0507009873554805f : y + 1.7580993408473766f;
+    return y > 0.f ? 1.f : 0.f;
+}
+
 // i / d for 0 <= i < 2^22 and a runtime d, with inv = 1.0f / d from the host: a float multiply and two
 // corrections instead of the ~40-instruction integer division sequence.
 __device__ __forceinline__ int fastdiv(int i, int d, float inv) {

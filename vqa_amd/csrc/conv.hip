@@ -87,6 +87,19 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     STAMP(0);
+    // 1-D grid of 8 * ceil(N / 8) workgroups over the N = tiles * B * (Cout / NB) units, channel block fastest: XCD k
+    // (workgroups k, k + 8, ...) takes the k-th contiguous eighth of the list, so the channel blocks of one tile and
+    // the tiles of one image - which read the same input rows - run side by side on ONE L2 (see unit_walk, common.h)
+    const int tiles_img = a.tiles_x * a.tiles_y, zb = a.Cout / NB, nunits = tiles_img * a.B * zb;
+    int unit = blockIdx.x;
+    if (VQA_XCD_WALK) {
+        const int k = blockIdx.x & 7;
+        unit = (int)(((long)nunits * k) >> 3) + (blockIdx.x >> 3);
+        if (unit >= (int)(((long)nunits * (k + 1)) >> 3)) return;
+    } else if (unit >= nunits) return;
+    const int ut = unit / zb;
+    const int co0 = (unit - ut * zb) * NB;
+    const int b = fastdiv(ut, tiles_img, a.inv_tiles), tile = ut - b * tiles_img;
     if constexpr (XF) {                                         // (read by the first stash: barrier below)
         for (int i = tid; i < a.Cin; i += 256) {
             coefl[i] = a.in_scale[i];
@@ -94,10 +107,8 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
         }
     }
     if constexpr (BST) {                                        // [4][NB] of this channel block (read in the epilogue)
-        for (int i = tid; i < 4 * NB; i += 256) coefl[i] = a.bn_coef[(i / NB) * a.Cout + blockIdx.z * NB + i % NB];
+        for (int i = tid; i < 4 * NB; i += 256) coefl[i] = a.bn_coef[(i / NB) * a.Cout + co0 + i % NB];
     }
-
-    const int tile = blockIdx.x, b = blockIdx.y, co0 = blockIdx.z * NB;
     const int ty = fastdiv(tile, a.tiles_x, a.inv_tx), tx = tile - ty * a.tiles_x;
     const int oy0 = ty * a.R, ox0 = tx * a.CW;
     const int MT = a.R * a.CW;
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
         __syncthreads();
         if (tid < NB * 2) {
             const float t = red[tid] + red[NB * 2 + tid] + red[2 * NB * 2 + tid] + red[3 * NB * 2 + tid];
-            const long blk = (long)b * gridDim.x + tile;
+            const long blk = (long)b * tiles_img + tile;
             a.stats[(blk * a.Cout + co0) * 2 + tid] = t;
         }
     }
@@ -467,8 +478,9 @@ __global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) vo
         }
     };
 
-    fetch(blockIdx.x);
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    const UnitWalk uw = unit_walk(blockIdx.x, gridDim.x, total);
+    fetch(uw.first);
+    for (int t = uw.first; t < uw.end; t += uw.step) {
         stash();
         __syncthreads();
         const int cb = fb, coy0 = foy0, cox0 = fox0;            // the tile being computed
@@ -489,7 +501,7 @@ __global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) vo
                 }
             }
         }
-        if (t + (int)gridDim.x < total) fetch(t + gridDim.x);
+        if (t + uw.step < uw.end) fetch(t + uw.step);
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -619,7 +631,7 @@ int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
     } else {
         if (G != total) return VQA_ERR_ARG;
         if ((double)a.B * a.IH * a.IW * a.Cin * sizeof(T) >= 2147483648.0) return VQA_ERR_ARG;   // (offset sentinel 2^31)
-        hipLaunchKernelGGL(kt, dim3(a.tiles_x * a.tiles_y, a.B, zb), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(kt, dim3(8 * ((total * zb + 7) / 8)), dim3(256), lds, s, a);
     }
     CHECK_LAUNCH();
     return VQA_OK;
@@ -778,11 +790,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
             if (i < (MTP << dsh)) *reinterpret_cast<uint4*>(dyl + (i >> dsh) * DYB + (i & (dvp - 1)) * 16) = t;
         }
     };
-    fetch(blockIdx.x);
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    const UnitWalk uw = unit_walk(blockIdx.x, gridDim.x, total);
+    fetch(uw.first);
+    for (int t = uw.first; t < uw.end; t += uw.step) {
         stash();
         __syncthreads();
-        if (t + (int)gridDim.x < total) fetch(t + gridDim.x);
+        if (t + uw.step < uw.end) fetch(t + uw.step);
         for (int ks = wk * KC; ks < MTP; ks += nwk * KC) {
             if constexpr (sizeof(T) == 2) {
                 // bf16: lane i = 4*rq + p of a 16-lane group supplies the address of k-row rq, channels 4p..4p+3;

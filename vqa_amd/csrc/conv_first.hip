@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
         ox0 = (tl - ty * a.tiles_x) * a.CW;
     };
     int fb, foy0, fox0;
-    tile_org(blockIdx.x, fb, foy0, fox0);
+    const UnitWalk uw = unit_walk(blockIdx.x, gridDim.x, total);
+    tile_org(uw.first, fb, foy0, fox0);
     fetch_pixels<TI>(a, ibuf, ibytes, plane, pl, fb, foy0, fox0, pv);
     // Loads and stores share one counter per wave (s_waitcnt vmcnt) and complete out of order with respect to each
     // other, so the wait for a tile's pixels is also a wait for every store issued before it.  The stores of tile t
@@ -223,12 +224,12 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
     // a whole iteration to complete, instead of the store round trip being exposed in every iteration.
     uint4 held[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
     unsigned hoff[2] = {ybytes, ybytes};                     // (buffer size = dropped)
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    for (int t = uw.first; t < uw.end; t += uw.step) {
         stash_pixels(smem, PP, pv);
         __syncthreads();
         const int b = fb, oy0 = foy0, ox0 = fox0;
-        if (t + (int)gridDim.x < total) {
-            tile_org(t + gridDim.x, fb, foy0, fox0);
+        if (t + uw.step < uw.end) {
+            tile_org(t + uw.step, fb, foy0, fox0);
             fetch_pixels<TI>(a, ibuf, ibytes, plane, pl, fb, foy0, fox0, pv);
         }
 #pragma unroll
@@ -383,9 +384,10 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
         }
         return make_uint4(ow[0], ow[1], ow[2], ow[3]);
     };
-    fetch(blockIdx.x);
+    const UnitWalk uw = unit_walk(blockIdx.x, gridDim.x, total);
+    fetch(uw.first);
     __syncthreads();                                              // (coef)
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    for (int t = uw.first; t < uw.end; t += uw.step) {
         stash_patch(patch, 3 * PP, pv);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
             if (i < MTP * 2) *reinterpret_cast<uint4*>(dyl + i * 16) = tv;
         }
         __syncthreads();
-        if (t + (int)gridDim.x < total) fetch(t + gridDim.x);
+        if (t + uw.step < uw.end) fetch(t + uw.step);
         for (int ks = wave * 32; ks < MTP; ks += 128) {
             bf16x8 fa, fb0, fb1;
 #pragma unroll

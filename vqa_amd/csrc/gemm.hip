@@ -62,7 +62,7 @@ __device__ __forceinline__ float epilogue_store(const GemmArgs& g, TC* C, int m,
         if (ne < g.N) {
             if (g.bias) x += g.bias[ne];
             if (g.rowadd) x += g.rowadd[(long)(m / g.rowadd_group) * g.N + ne];
-            if (g.act == 1) x = fmaxf(x, 0.f);
+            if (g.act == 1 || g.act == 3) x = act_apply(x, g.act);
             if (g.accumulate) x += to_f32(C[(long)m * g.ldc + ne]);
             if (g.act == 2) {                      // the arithmetic of bce_partial (misc.hip), element for element
                 const float t = g.target ? g.target[(long)m * g.ldt + ne] : 0.f;
@@ -381,6 +381,9 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
                     if (g.act == 1) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    } else if (g.act == 3) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = selu_f(v[e]);
                     }
                     if (g.accumulate) {
 #pragma unroll
@@ -445,7 +448,7 @@ __global__ void gemm_splitk_reduce(GemmArgs g, int splits) {
         for (int e = 0; e < V; ++e) {
             if (g.bias) x[e] += g.bias[n + e];
             if (g.rowadd) x[e] += g.rowadd[(m / g.rowadd_group) * g.N + n + e];
-            if (g.act == 1) x[e] = fmaxf(x[e], 0.f);
+            if (g.act == 1 || g.act == 3) x[e] = act_apply(x[e], g.act);
             if (g.accumulate) x[e] += to_f32(C[m * g.ldc + n + e]);
         }
         if constexpr (VEC4) {
@@ -530,7 +533,7 @@ extern "C" int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K,
     const int kc = dtype == VQA_BF16 ? 128 : 16;   // split boundaries on whole pipeline stages
     const int kper = ((K + splits - 1) / splits + kc - 1) / kc * kc;
     splits = splits > 1 ? (K + kper - 1) / kper : 1;
-    if (act != 0 && act != 1) return VQA_ERR_ARG;
+    if (act != 0 && act != 1 && act != 3) return VQA_ERR_ARG;
     GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, bias, rowadd, rowadd_group, act, accumulate,
                static_cast<bf16*>(C2), ldc2, splits > 1 ? splitk_ws : nullptr, kper, nullptr, 0, nullptr, 0, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -27,7 +27,7 @@ extern "C" int vqa_gru_fwd_steps(void* stream, int dtype, const float* gi, const
 
 extern "C" int vqa_gru_bwd_steps(void* stream, int dtype, const float* dh_last, const float* save, const float* h_f,
                                  const void* w_hh_t, int ldw, void* dgi, void* dgh, float* dh_ws, float* splitk_ws,
-                                 int splits, int B, int T, int H) {
+                                 int splits, int B, int T, int H, const float* dh_seq) {
     if (B < 1 || T < 1 || H < 1 || !dh_last || !save || !h_f || !w_hh_t || !dgi || !dgh || !dh_ws) return VQA_ERR_ARG;
     const size_t esz = dtype == VQA_BF16 ? 2 : 4;
     const long bh = (long)B * H, b3 = (long)B * 3 * H;
@@ -36,7 +36,10 @@ extern "C" int vqa_gru_bwd_steps(void* stream, int dtype, const float* dh_last, 
         float* dprev = dh_ws + (t & 1) * bh;              // (never the buffer dh points to: they alternate)
         char* gi_t = static_cast<char*>(dgi) + (size_t)t * b3 * esz;
         char* gh_t = static_cast<char*>(dgh) + (size_t)t * b3 * esz;
-        int st = vqa_gru_gate_bwd(stream, dtype, dh, save + (long)t * B * 4 * H, h_f + t * bh, B, H, gi_t, gh_t, dprev);
+        // dh_seq (multi-layer GRU, may be NULL): [T][B][H] gradient of the layer above w.r.t. every step's output; the
+        // caller has added dh_seq[T-1] into dh_last, step t adds dh_seq[t-1] to the gradient of h_{t-1}
+        int st = vqa_gru_gate_bwd(stream, dtype, dh, save + (long)t * B * 4 * H, h_f + t * bh, B, H, gi_t, gh_t, dprev,
+                                  (dh_seq && t > 0) ? dh_seq + (t - 1) * bh : nullptr);
         if (st != VQA_OK) return st;
         if (t > 0) {                                      // dh_{t-1} += dgh_t @ W_hh
             st = vqa_gemm(stream, dtype, 0, B, H, 3 * H, gh_t, 3 * H, w_hh_t, ldw, dprev, H, VQA_F32, nullptr, nullptr, 1,

@@ -282,7 +282,7 @@ __global__ void gru_gate_fwd(const float* __restrict__ gi, const float* __restri
 template <typename T>
 __global__ void gru_gate_bwd(const float* __restrict__ dh, const float* __restrict__ save,
                              const float* __restrict__ hprev, int B, int H, T* __restrict__ dgi, T* __restrict__ dgh,
-                             float* __restrict__ dhprev) {
+                             float* __restrict__ dhprev, const float* __restrict__ dh_add) {
     const int HV = H / 4;
     const long total = (long)B * HV;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -300,6 +300,12 @@ __global__ void gru_gate_bwd(const float* __restrict__ dh, const float* __restri
             dr[e] = dn[e] * hn[e] * r[e] * (1.f - r[e]);
             dnr[e] = dn[e] * r[e];
             dp[e] = g[e] * z[e];
+        }
+        if (dh_add) {      // multi-layer GRU: the layer above also feeds on h_{t-1} (its input-projection gradient)
+            float ad[4];
+            load4(dh_add + b * H + j, ad);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp[e] += ad[e];
         }
         T* a = dgi + b * 3 * H + j;
         T* c = dgh + b * 3 * H + j;
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256) void attn_bwd(const T* __restrict__ a, const T
                                                 const float* __restrict__ v, const float* __restrict__ p,
                                                 const float* __restrict__ dvhat, int K, int H, int D,
                                                 float* __restrict__ dv, T* __restrict__ dpre,
-                                                float* __restrict__ dws_part) {
+                                                float* __restrict__ dws_part, int act) {
     constexpr int N = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float sm[];  // ds[K], then the dws combine
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(256) void attn_bwd(const T* __restrict__ a, const T
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
                     acc[e] += dsk * av[e];
-                    o[e] = av[e] > 0.f ? dsk * w[e] : 0.f;
+                    o[e] = dsk * w[e] * act_grad(av[e], act);
                 }
                 Vec16<T>::store(dpre + ((long)b * K + k) * H + jv * N, o);
             }
@@ -504,33 +510,35 @@ __global__ void group_sum(const T* x, int B, int K, int H, float* out, T* out_t)
 }
 
 // ---------------------------------------------------------------------------------------- head elementwise
-// m0 = fv * fq * mask  (mask may be null; mask already carries the 1/(1-p) dropout scale)
+// m0 = fv * fq * mask + add  (either may be null).  nn.Dropout: mask = keep / (1-p), no add.  nn.AlphaDropout
+// (vqa_model.py:55, the selu branch): a * (x * keep + alpha' * (1 - keep)) + b = x * (a * keep) + (a * alpha' *
+// (1 - keep) + b): mask = a * keep, add = the second term; the backward needs the mask only.
 template <typename T>
-__global__ void hadamard_fwd(const float* fv, const float* fq, const float* mask, long n, T* out) {
+__global__ void hadamard_fwd(const float* fv, const float* fq, const float* mask, const float* add, long n, T* out) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        out[i] = from_f32<T>(fv[i] * fq[i] * (mask ? mask[i] : 1.f));
+        out[i] = from_f32<T>(fv[i] * fq[i] * (mask ? mask[i] : 1.f) + (add ? add[i] : 0.f));
 }
-// dpre_v = dm0*mask*fq*1[fv>0], dpre_q = dm0*mask*fv*1[fq>0]     (fv, fq are post-ReLU)
+// dpre_v = dm0*mask*fq*act'(fv), dpre_q = dm0*mask*fv*act'(fq)     (fv, fq are post-activation; act' from the output)
 template <typename T>
 __global__ void hadamard_bwd(const float* dm0, const float* fv, const float* fq, const float* mask, long n, T* dpv,
-                             T* dpq) {
+                             T* dpq, int act) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float g = dm0[i] * (mask ? mask[i] : 1.f);
-        dpv[i] = from_f32<T>(fv[i] > 0.f ? g * fq[i] : 0.f);
-        dpq[i] = from_f32<T>(fq[i] > 0.f ? g * fv[i] : 0.f);
+        dpv[i] = from_f32<T>(g * fq[i] * act_grad(fv[i], act));
+        dpq[i] = from_f32<T>(g * fv[i] * act_grad(fq[i], act));
     }
 }
-// out = g * mask * 1[act > 0]
+// out = g * mask * act'(y)      (y = the activation's output)
 template <typename T>
-__global__ void relu_bwd(const float* g, const float* act, const float* mask, long n, T* out) {
+__global__ void relu_bwd(const float* g, const float* y, const float* mask, long n, T* out, int act) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        out[i] = from_f32<T>(act[i] > 0.f ? g[i] * (mask ? mask[i] : 1.f) : 0.f);
+        out[i] = from_f32<T>(g[i] * (mask ? mask[i] : 1.f) * act_grad(y[i], act));
 }
-// out = x * mask (f32 + MFMA-dtype copy)
+// out = x * mask + add (MFMA-dtype copy; see hadamard_fwd)
 template <typename T>
-__global__ void mask_mul(const float* x, const float* mask, long n, T* out) {
+__global__ void mask_mul(const float* x, const float* mask, const float* add, long n, T* out) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        out[i] = from_f32<T>(x[i] * (mask ? mask[i] : 1.f));
+        out[i] = from_f32<T>(x[i] * (mask ? mask[i] : 1.f) + (add ? add[i] : 0.f));
 }
 
 // ---------------------------------------------------------------------------------------- loss / accuracy
@@ -806,11 +814,11 @@ extern "C" int vqa_gru_gate_fwd(void* stream, int dtype, const float* gi, const 
 }
 
 extern "C" int vqa_gru_gate_bwd(void* stream, int dtype, const float* dh, const float* save, const float* hprev, int B,
-                                int H, void* dgi, void* dgh, float* dhprev) {
+                                int H, void* dgi, void* dgh, float* dhprev, const float* dh_add) {
     if (H % 4) return VQA_ERR_ARG;
     dim3 grid((unsigned)(((long)B * (H / 4) + 255) / 256));
-    BY_T(dtype, hipLaunchKernelGGL(gru_gate_bwd<bf16>, grid, dim3(256), 0, ST, dh, save, hprev, B, H, (bf16*)dgi, (bf16*)dgh, dhprev),
-         hipLaunchKernelGGL(gru_gate_bwd<float>, grid, dim3(256), 0, ST, dh, save, hprev, B, H, (float*)dgi, (float*)dgh, dhprev));
+    BY_T(dtype, hipLaunchKernelGGL(gru_gate_bwd<bf16>, grid, dim3(256), 0, ST, dh, save, hprev, B, H, (bf16*)dgi, (bf16*)dgh, dhprev, dh_add),
+         hipLaunchKernelGGL(gru_gate_bwd<float>, grid, dim3(256), 0, ST, dh, save, hprev, B, H, (float*)dgi, (float*)dgh, dhprev, dh_add));
     CHECK_LAUNCH();
     return VQA_OK;
 }
@@ -829,13 +837,14 @@ extern "C" int vqa_attn_fwd(void* stream, int dtype, const void* a, const void* 
 }
 
 extern "C" int vqa_attn_bwd(void* stream, int dtype, const void* a, const void* ws, const float* v, const float* p,
-                            const float* dvhat, int B, int K, int H, int D, float* dv, void* dpre, float* dws_part) {
+                            const float* dvhat, int B, int K, int H, int D, float* dv, void* dpre, float* dws_part,
+                            int act) {
     const int N = dtype == VQA_BF16 ? 8 : 4;
-    if (K < 1 || H % N || D % 4) return VQA_ERR_ARG;
+    if (K < 1 || H % N || D % 4 || (act != VQA_ACT_RELU && act != VQA_ACT_SELU)) return VQA_ERR_ARG;
     // ds[K] + the dws combine: per round min(H/N, 256) vectors x (256 / that) row residues x N floats <= 256 * N floats
     const size_t lds = ((size_t)(K + 3) / 4 * 4 + (size_t)256 * N) * sizeof(float);
-    BY_T(dtype, hipLaunchKernelGGL(attn_bwd<bf16>, dim3(B), dim3(256), lds, ST, (const bf16*)a, (const bf16*)ws, v, p, dvhat, K, H, D, dv, (bf16*)dpre, dws_part),
-         hipLaunchKernelGGL(attn_bwd<float>, dim3(B), dim3(256), lds, ST, (const float*)a, (const float*)ws, v, p, dvhat, K, H, D, dv, (float*)dpre, dws_part));
+    BY_T(dtype, hipLaunchKernelGGL(attn_bwd<bf16>, dim3(B), dim3(256), lds, ST, (const bf16*)a, (const bf16*)ws, v, p, dvhat, K, H, D, dv, (bf16*)dpre, dws_part, act),
+         hipLaunchKernelGGL(attn_bwd<float>, dim3(B), dim3(256), lds, ST, (const float*)a, (const float*)ws, v, p, dvhat, K, H, D, dv, (float*)dpre, dws_part, act));
     CHECK_LAUNCH();
     return VQA_OK;
 }
@@ -859,36 +868,39 @@ extern "C" int vqa_group_sum(void* stream, int dtype, const void* x, int B, int 
 }
 
 extern "C" int vqa_hadamard_fwd(void* stream, int dtype, const float* fv, const float* fq, const float* mask, long n,
-                                void* out) {
+                                void* out, const float* add) {
     dim3 grid(grid1d(n));
-    BY_T(dtype, hipLaunchKernelGGL(hadamard_fwd<bf16>, grid, dim3(256), 0, ST, fv, fq, mask, n, (bf16*)out),
-         hipLaunchKernelGGL(hadamard_fwd<float>, grid, dim3(256), 0, ST, fv, fq, mask, n, (float*)out));
+    BY_T(dtype, hipLaunchKernelGGL(hadamard_fwd<bf16>, grid, dim3(256), 0, ST, fv, fq, mask, add, n, (bf16*)out),
+         hipLaunchKernelGGL(hadamard_fwd<float>, grid, dim3(256), 0, ST, fv, fq, mask, add, n, (float*)out));
     CHECK_LAUNCH();
     return VQA_OK;
 }
 
 extern "C" int vqa_hadamard_bwd(void* stream, int dtype, const float* dm0, const float* fv, const float* fq,
-                                const float* mask, long n, void* dpv, void* dpq) {
+                                const float* mask, long n, void* dpv, void* dpq, int act) {
+    if (act != VQA_ACT_RELU && act != VQA_ACT_SELU) return VQA_ERR_ARG;
     dim3 grid(grid1d(n));
-    BY_T(dtype, hipLaunchKernelGGL(hadamard_bwd<bf16>, grid, dim3(256), 0, ST, dm0, fv, fq, mask, n, (bf16*)dpv, (bf16*)dpq),
-         hipLaunchKernelGGL(hadamard_bwd<float>, grid, dim3(256), 0, ST, dm0, fv, fq, mask, n, (float*)dpv, (float*)dpq));
+    BY_T(dtype, hipLaunchKernelGGL(hadamard_bwd<bf16>, grid, dim3(256), 0, ST, dm0, fv, fq, mask, n, (bf16*)dpv, (bf16*)dpq, act),
+         hipLaunchKernelGGL(hadamard_bwd<float>, grid, dim3(256), 0, ST, dm0, fv, fq, mask, n, (float*)dpv, (float*)dpq, act));
     CHECK_LAUNCH();
     return VQA_OK;
 }
 
-extern "C" int vqa_relu_bwd(void* stream, int dtype, const float* g, const float* act, const float* mask, long n,
-                            void* out) {
+extern "C" int vqa_relu_bwd(void* stream, int dtype, const float* g, const float* y, const float* mask, long n,
+                            void* out, int act) {
+    if (act != VQA_ACT_RELU && act != VQA_ACT_SELU) return VQA_ERR_ARG;
     dim3 grid(grid1d(n));
-    BY_T(dtype, hipLaunchKernelGGL(relu_bwd<bf16>, grid, dim3(256), 0, ST, g, act, mask, n, (bf16*)out),
-         hipLaunchKernelGGL(relu_bwd<float>, grid, dim3(256), 0, ST, g, act, mask, n, (float*)out));
+    BY_T(dtype, hipLaunchKernelGGL(relu_bwd<bf16>, grid, dim3(256), 0, ST, g, y, mask, n, (bf16*)out, act),
+         hipLaunchKernelGGL(relu_bwd<float>, grid, dim3(256), 0, ST, g, y, mask, n, (float*)out, act));
     CHECK_LAUNCH();
     return VQA_OK;
 }
 
-extern "C" int vqa_mask_mul(void* stream, int dtype, const float* x, const float* mask, long n, void* out) {
+extern "C" int vqa_mask_mul(void* stream, int dtype, const float* x, const float* mask, long n, void* out,
+                            const float* add) {
     dim3 grid(grid1d(n));
-    BY_T(dtype, hipLaunchKernelGGL(mask_mul<bf16>, grid, dim3(256), 0, ST, x, mask, n, (bf16*)out),
-         hipLaunchKernelGGL(mask_mul<float>, grid, dim3(256), 0, ST, x, mask, n, (float*)out));
+    BY_T(dtype, hipLaunchKernelGGL(mask_mul<bf16>, grid, dim3(256), 0, ST, x, mask, add, n, (bf16*)out),
+         hipLaunchKernelGGL(mask_mul<float>, grid, dim3(256), 0, ST, x, mask, add, n, (float*)out));
     CHECK_LAUNCH();
     return VQA_OK;
 }

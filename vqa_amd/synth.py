@@ -75,7 +75,7 @@ def targets(seed, batch, classes=3129):
     return t
 
 
-def state_dict_spec(hidden, classes, vocab, word_dim=300, img_dim=256):
+def state_dict_spec(hidden, classes, vocab, word_dim=300, img_dim=256, n_layers=1):
     """(name, shape, kind) for every parameter/buffer of the reference VQA module, in state_dict order.
 
     Names/shapes as printed by importing the reference (reference cnn.py:22-42,
@@ -93,11 +93,12 @@ def state_dict_spec(hidden, classes, vocab, word_dim=300, img_dim=256):
                  (f'cnn.convolutions.{si + 1}.running_var', (cout,), ('range', 0.5, 1.5)),
                  (f'cnn.convolutions.{si + 1}.num_batches_tracked', (), ('zero_long',))]
     H = hidden
-    spec += [('gru.word_embedding.weight', (vocab, word_dim), ('range', -1.5, 1.5)),
-             ('gru.encoder.weight_ih_l0', (3 * H, word_dim), ('fan', H)),
-             ('gru.encoder.weight_hh_l0', (3 * H, H), ('fan', H)),
-             ('gru.encoder.bias_ih_l0', (3 * H,), ('fan', H)),
-             ('gru.encoder.bias_hh_l0', (3 * H,), ('fan', H))]
+    spec += [('gru.word_embedding.weight', (vocab, word_dim), ('range', -1.5, 1.5))]
+    for k in range(n_layers):                                # nn.GRU(num_layers=n_layers), gru.py:51
+        spec += [(f'gru.encoder.weight_ih_l{k}', (3 * H, word_dim if k == 0 else H), ('fan', H)),
+                 (f'gru.encoder.weight_hh_l{k}', (3 * H, H), ('fan', H)),
+                 (f'gru.encoder.bias_ih_l{k}', (3 * H,), ('fan', H)),
+                 (f'gru.encoder.bias_hh_l{k}', (3 * H,), ('fan', H))]
     for nm, out, inn, bias in [('linear_inside_relu_attention', H, img_dim + H, True),
                                ('linear_after_relu_attention', 1, H, False),
                                ('linear_inside_relu_image', H, img_dim, True),
@@ -112,10 +113,10 @@ def state_dict_spec(hidden, classes, vocab, word_dim=300, img_dim=256):
     return spec
 
 
-def state_dict(seed, hidden, classes, vocab, word_dim=300, img_dim=256):
+def state_dict(seed, hidden, classes, vocab, word_dim=300, img_dim=256, n_layers=1):
     """Deterministic full state_dict for the VQA module (loads into the reference and into the build)."""
     sd = {}
-    for name, shape, kind in state_dict_spec(hidden, classes, vocab, word_dim, img_dim):
+    for name, shape, kind in state_dict_spec(hidden, classes, vocab, word_dim, img_dim, n_layers):
         if kind[0] == 'fan':
             b = 1.0 / float(kind[1]) ** 0.5
             shift = kind[2] * b if len(kind) > 2 else 0.0

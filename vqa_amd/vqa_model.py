@@ -66,6 +66,16 @@ class WeightNormLinear(nn.Module):
         self.weight_v = nn.Parameter(lin.weight.detach().clone())
 
 
+def alpha_dropout_noise(keep, p=0.5):
+    """nn.AlphaDropout's noise as torch forms it (ATen Dropout.cpp, alpha dropout): with alpha' = 1.7580993408473766
+    and a = ((alpha'^2 p + 1)(1 - p))^-1/2 the output is x * (a * keep) + ((keep - 1) * alpha' * a + alpha' * a * p).
+    keep: 0/1 tensor.  Returns (mask, add) for the head's dropout sites."""
+    alpha = 1.7580993408473766
+    a = 1.0 / ((alpha * alpha * p + 1.0) * (1.0 - p)) ** 0.5
+    keep = keep.float()
+    return keep * a, (keep - 1.0) * (alpha * a) + alpha * a * p
+
+
 HEAD_LAYERS = ['linear_inside_relu_attention', 'linear_after_relu_attention', 'linear_inside_relu_image',
                'linear_inside_relu_question', 'linear_inside_relu_last', 'fc']
 
@@ -81,13 +91,15 @@ class _HeadFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, v, q, dtype, masks, target, g_att, v_att, b_att, g_s, v_s, g_img, v_img, b_img, g_q, v_q, b_q,
-                g_last, v_last, b_last, g_fc, v_fc):
+                g_last, v_last, b_last, g_fc, v_fc, act=1):
+        # act: 1 = nn.ReLU, 3 = nn.SELU (vqa_model.py:54).  masks = (mask1, mask2, add1, add2): the two dropout sites
+        # compute x * mask + add (nn.Dropout: add None; nn.AlphaDropout: see _alpha_dropout_noise)
         B, K, D = v.shape
         H, C = v_q.shape[0], v_fc.shape[0]
         dev = v.device
         v = v.contiguous()
         q = q.contiguous()
-        mask1, mask2 = masks
+        mask1, mask2, add1, add2 = masks
         # all six weight-normed layers: W = g * v / ||v||_F (and W^T for the backward) in two launches
         wn, ss = ops.weight_norm_fwd_all([(v_att, g_att, True), (v_s, g_s, False), (v_img, g_img, True),
                                           (v_q, g_q, True), (v_last, g_last, True), (v_fc, g_fc, True)], dtype)
@@ -96,21 +108,21 @@ class _HeadFunction(torch.autograd.Function):
         v_t = ops.cast_pad(v.reshape(B * K, D), dtype)
         q_t = ops.cast_pad(q, dtype)
         qa = ops.gemm(q_t, W_att[:, D:], bias=b_att)                                        # [B,H]
-        a = ops.gemm(v_t, W_att[:, :D], out_dtype=dtype, rowadd=qa, group=K, act=1)         # [B*K,H]
+        a = ops.gemm(v_t, W_att[:, :D], out_dtype=dtype, rowadd=qa, group=K, act=act)       # [B*K,H]
         p = torch.empty(B, K, device=dev, dtype=torch.float32)
         vhat = torch.empty(B, D, device=dev, dtype=torch.float32)
         vhat_t = torch.empty(B, D, device=dev, dtype=dtype)
         L.call('vqa_attn_fwd', L.dt(a), a, w_s, v, B, K, H, D, p, vhat, vhat_t)
-        fv = ops.gemm(vhat_t, W_img, bias=b_img, act=1)
-        fq = ops.gemm(q_t, W_q, bias=b_q, act=1)
+        fv = ops.gemm(vhat_t, W_img, bias=b_img, act=act)
+        fq = ops.gemm(q_t, W_q, bias=b_q, act=act)
         m0 = torch.empty(B, H, device=dev, dtype=dtype)
-        L.call('vqa_hadamard_fwd', L.dt(m0), fv, fq, mask1, B * H, m0)
+        L.call('vqa_hadamard_fwd', L.dt(m0), fv, fq, mask1, B * H, m0, add1)
         m_t = torch.empty(B, H, device=dev, dtype=dtype)
-        if mask2 is None and dtype == torch.bfloat16:
-            m = ops.gemm(m0, W_last, bias=b_last, act=1, c2=m_t)      # no dropout: the GEMM writes the bf16 copy itself
+        if mask2 is None and add2 is None and dtype == torch.bfloat16:
+            m = ops.gemm(m0, W_last, bias=b_last, act=act, c2=m_t)    # no dropout: the GEMM writes the bf16 copy itself
         else:
-            m = ops.gemm(m0, W_last, bias=b_last, act=1)
-            L.call('vqa_mask_mul', L.dt(m_t), m, mask2, B * H, m_t)
+            m = ops.gemm(m0, W_last, bias=b_last, act=act)
+            L.call('vqa_mask_mul', L.dt(m_t), m, mask2, B * H, m_t, add2)
         if target is None:
             logits, loss, dl = ops.gemm(m_t, W_fc), None, None
         else:
@@ -119,8 +131,9 @@ class _HeadFunction(torch.autograd.Function):
         ctx.save_for_backward(v, q_t, v_t, a, w_s, p, vhat_t, fv, fq, m0, m, m_t, W_att_T, W_img_T, W_q_T, W_last_T,
                               W_fc_T, ss, g_att, v_att, g_s, v_s, g_img, v_img,
                               g_q, v_q, g_last, v_last, g_fc, v_fc, b_att, b_img, b_q, b_last,
-                              *[t for t in masks if t is not None], *([dl] if dl is not None else []))
+                              *[t for t in (mask1, mask2) if t is not None], *([dl] if dl is not None else []))
         ctx.dims, ctx.dtype, ctx.has_masks = (B, K, D, H, C), dtype, (mask1 is not None, mask2 is not None)
+        ctx.act = act
         ctx.fused_loss = dl is not None
         ctx.set_materialize_grads(False)
         return logits, loss
@@ -135,7 +148,7 @@ class _HeadFunction(torch.autograd.Function):
         mask2 = extra.pop(0) if ctx.has_masks[1] else None
         dl_saved = extra.pop(0) if ctx.fused_loss else None
         B, K, D, H, C = ctx.dims
-        dtype, dev = ctx.dtype, v.device
+        dtype, dev, act = ctx.dtype, v.device, ctx.act
         new = lambda *s, dt=dtype: torch.empty(*s, device=dev, dtype=dt)
 
         ops.defer_reset()
@@ -151,16 +164,16 @@ class _HeadFunction(torch.autograd.Function):
             dl_t = ops.cast_pad(dlogits.contiguous(), dtype, ops.pad8(C))        # [B,C] (padded rows)
         dm = ops.gemm(dl_t, W_fc_T)                                              # [B,H]
         dpre_last = new(B, H)
-        L.call('vqa_relu_bwd', L.dt(dpre_last), dm, m, mask2, B * H, dpre_last)
+        L.call('vqa_relu_bwd', L.dt(dpre_last), dm, m, mask2, B * H, dpre_last, act)
         dm0 = ops.gemm(dpre_last, W_last_T)
         dpv, dpq = new(B, H), new(B, H)
-        L.call('vqa_hadamard_bwd', L.dt(dpv), dm0, fv, fq, mask1, B * H, dpv, dpq)
+        L.call('vqa_hadamard_bwd', L.dt(dpv), dm0, fv, fq, mask1, B * H, dpv, dpq, act)
         dvhat = ops.gemm(dpv, W_img_T)                                           # [B,D]
         dq = ops.gemm(dpq, W_q_T)                                                # [B,H]
         dv = new(B * K, D, dt=torch.float32)
         dpre_a = new(B * K, H)
         dws_part = new(B, H, dt=torch.float32)
-        L.call('vqa_attn_bwd', L.dt(a), a, w_s, v, p, dvhat, B, K, H, D, dv, dpre_a, dws_part)
+        L.call('vqa_attn_bwd', L.dt(a), a, w_s, v, p, dvhat, B, K, H, D, dv, dpre_a, dws_part, act)
         ops.gemm(dpre_a, W_att_T[:D], out=dv, accumulate=True)                   # += dpre_a @ W_v
         dqa, dqa_t = new(B, H, dt=torch.float32), new(B, H)
         L.call('vqa_group_sum', L.dt(dpre_a), dpre_a, B, K, H, dqa, dqa_t)
@@ -213,7 +226,7 @@ class _HeadFunction(torch.autograd.Function):
             wn, db_att, db_img, db_q, db_last = weights()
         (dg_att, dv_att), (dg_s, dv_s), (dg_img, dv_img), (dg_q, dv_q), (dg_last, dv_last), (dg_fc, dv_fc) = wn
         return (dv.reshape(B, K, D), dq, None, None, None, dg_att, dv_att, db_att, dg_s, dv_s, dg_img, dv_img, db_img,
-                dg_q, dv_q, db_q, dg_last, dv_last, db_last, dg_fc, dv_fc)
+                dg_q, dv_q, db_q, dg_last, dv_last, db_last, dg_fc, dv_fc, None)
 
 
 class VQA(nn.Module):
@@ -223,9 +236,6 @@ class VQA(nn.Module):
         super(VQA, self).__init__()
         running_on_linux = 'Linux' in platform.platform()  # noqa: F841
         self.device = 'cuda:0' if torch.cuda.is_available() else 'cpu'
-        if activation != 'relu':
-            raise NotImplementedError("the HIP head implements activation='relu' (every reference run config); "
-                                      "the selu / AlphaDropout branch is not built")
         self.precision = precision
         self.cnn = cnn.CNN(padding=padding, pooling=pooling, precision=precision)
         self.padding = padding
@@ -255,12 +265,21 @@ class VQA(nn.Module):
         self.precision = self.cnn.precision = self.gru.precision = precision
         return self
 
+    ALPHA_DROPOUT_P = 0.5       # the reference's selu branch builds nn.AlphaDropout() with torch's default p
+
     def _dropout_mask(self, B, dev):
-        # inverted dropout (nn.Dropout, vqa_model.py:55): keep-mask scaled by 1/(1-p); identity at p=0 / eval
-        if not self.training or self.dropout_p <= 0.0:
-            return None
-        keep = 1.0 - self.dropout_p
-        return torch.empty(B, self.hidden_dim, device=dev).bernoulli_(keep).div_(keep)
+        """(mask, add) of one dropout site, out = x * mask + add; (None, None) = identity (eval, or nn.Dropout(0)).
+        activation == 'relu': nn.Dropout(dropout) - inverted dropout, keep-mask scaled by 1/(1-p).
+        any other activation: nn.AlphaDropout() (vqa_model.py:55 ignores `dropout` there: p = 0.5)."""
+        if not self.training:
+            return None, None
+        if self.activation == 'relu':
+            if self.dropout_p <= 0.0:
+                return None, None
+            keep = 1.0 - self.dropout_p
+            return torch.empty(B, self.hidden_dim, device=dev).bernoulli_(keep).div_(keep), None
+        return alpha_dropout_noise(torch.empty(B, self.hidden_dim, device=dev).bernoulli_(1.0 - self.ALPHA_DROPOUT_P),
+                                   self.ALPHA_DROPOUT_P)
 
     def forward_loss(self, images_batch, questions_batch, target, mirror=False, dropout_noise=None):
         """forward() and the reference's criterion (nn.BCEWithLogitsLoss(reduction='sum'), vqa_model.py:215, :255) in
@@ -300,17 +319,22 @@ class VQA(nn.Module):
         dtype = torch.bfloat16 if self.precision == 'bf16' else torch.float32
         B, dev = images_representation.shape[0], images_representation.device
         if dropout_noise is not None:
-            masks = tuple(None if t is None else t.to(dev, torch.float32).contiguous() for t in dropout_noise)
-            assert all(t is None or tuple(t.shape) == (B, self.hidden_dim) for t in masks)
+            # per site: a multiplicative noise tensor [B,H] (nn.Dropout), a (mask, add) pair (nn.AlphaDropout,
+            # alpha_dropout_noise(keep)), or None
+            sites = [t if isinstance(t, (tuple, list)) else (t, None) for t in dropout_noise]
+            sites = [tuple(None if t is None else t.to(dev, torch.float32).contiguous() for t in st) for st in sites]
+            assert all(t is None or tuple(t.shape) == (B, self.hidden_dim) for st in sites for t in st)
         else:
-            masks = (self._dropout_mask(B, dev), self._dropout_mask(B, dev))
+            sites = [self._dropout_mask(B, dev), self._dropout_mask(B, dev)]
+        masks = (sites[0][0], sites[1][0], sites[0][1], sites[1][1])
+        act = 1 if self.activation == 'relu' else 3         # vqa_model.py:54: anything but 'relu' is nn.SELU()
         a, s, i, qq, l, f = (getattr(self, n) for n in HEAD_LAYERS)
         if target is not None and not isinstance(target, (tuple, list)):
             target = target.float()
         logits, loss = _HeadFunction.apply(images_representation, questions_representation, dtype, masks, target,
                                    a.weight_g, a.weight_v, a.bias, s.weight_g, s.weight_v, i.weight_g, i.weight_v,
                                    i.bias, qq.weight_g, qq.weight_v, qq.bias, l.weight_g, l.weight_v, l.bias,
-                                   f.weight_g, f.weight_v)
+                                   f.weight_g, f.weight_v, act)
         return logits if target is None else (logits, loss)
 
 

@@ -195,6 +195,21 @@ int vqa_gru_bwd_steps(void* stream, int dtype, const float* dh_last, const float
                       const void* w_hh_t, int ldw, void* dgi, void* dgh, float* dh_ws, float* splitk_ws, int splits,
                       int B, int T, int H, const float* dh_seq);
 
+/* The same recurrence (gru.py:104) with ONE launch per time step (csrc/gru_step.hip): the recurrent GEMM streams both
+ * operands, kept in MFMA-fragment order in memory, straight into registers (no LDS staging, no split-K pass) and the
+ * gate arithmetic runs in its epilogue on the accumulators - gh (forward) and the dh round trip (backward) never
+ * exist in memory.  bf16 only, H % 64 == 0; status 1 = shape not served (nothing launched): use the *_steps form.
+ *   vqa_gru_pack_whh   f32 master W_hh [3H][H] -> wf (forward operand) and / or wb (W_hh^T, backward operand), 3 H H
+ *                      bf16 each, either may be NULL; once per training step, replaces the cast and the transposed copy
+ *   vqa_gru_fwd_fused  as vqa_gru_fwd_steps; h_p = scratch of (T+1) x P(H) bf16, P(k) = ceil(B/64) * 64 * k: the
+ *                      packed h_t each step writes for the next one (slot 0 is never read)
+ *   vqa_gru_bwd_fused  as vqa_gru_bwd_steps; dgh_p = scratch of 2 x P(3H) bf16 */
+int vqa_gru_pack_whh(void* stream, const float* w_hh, int H, void* wf, void* wb);
+int vqa_gru_fwd_fused(void* stream, const float* gi, const void* wf, const float* b_hh, float* h_f, void* h_t, void* h_p,
+                      float* save, int B, int T, int H);
+int vqa_gru_bwd_fused(void* stream, const float* dh_last, const float* save, const float* h_f, const void* wb, void* dgi,
+                      void* dgh, void* dgh_p, float* dh_ws, int B, int T, int H, const float* dh_seq);
+
 /* The whole nn.GRU recurrence (gru.py:104) in ONE persistent launch: each workgroup keeps its 48 x H slice of W_hh
  * (bf16) in LDS for all T steps, gates fused in registers, one device-wide barrier per step.  The grid is sized to be
  * co-resident (occupancy query x CUs; max_wg > 0 caps it lower so the recurrence holds fewer CUs beside other work).

@@ -9,8 +9,8 @@ with tempfile.TemporaryDirectory() as tmp:
 B, T = 256, 14
 q = synth.questions(1, B, T, 10000).cuda()
 dh = torch.randn(B, 1024, device='cuda')
-for use in (True, False, True, False):
-    G.USE_PERSISTENT = use
+for use, fused in ((False, True), (False, False), (True, False), (False, True), (False, False)):
+    G.USE_PERSISTENT, G.FUSED_STEP = use, fused
     for it in range(3):
         g.zero_grad()
         torch.cuda.synchronize()
@@ -21,4 +21,4 @@ for use in (True, False, True, False):
         (h * dh).sum().backward()
         e2.record()
         torch.cuda.synchronize()
-    print(f'persistent={use}: fwd {e0.elapsed_time(e1):.3f} ms  bwd {e1.elapsed_time(e2):.3f} ms')
+    print(f'persistent={use} fused_step={fused}: fwd {e0.elapsed_time(e1):.3f} ms  bwd {e1.elapsed_time(e2):.3f} ms')

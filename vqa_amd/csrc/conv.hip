@@ -83,6 +83,8 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     unsigned char* patch = smem;
     unsigned char* wl = smem + (a.R + 2) * PROWB;
     float* coefl = reinterpret_cast<float*>(wl + NB * WROWB);   // XF: [2][Cin] input scale / shift
+    // byte offset (from `patch`) of the 4 KB dump area behind the coefficient rows (see the staging plan)
+    const int dump = (a.R + 2) * PROWB + NB * WROWB + NB * 4 + 2 * a.Cin * 4 + 4 * NB * 4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -114,6 +116,71 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     const int MT = a.R * a.CW;
     const T* w = static_cast<const T*>(a.w);
 
+    // ---- staging plan.  Every thread moves up to NPV patch vectors and NWV weight vectors per channel chunk.  The
+    // loads are branch-free (out-of-image / out-of-range lanes read a valid dummy address and are zeroed by a
+    // select) so that all of a chunk's loads are in flight together, and the loads of chunk ch+1 are issued before
+    // the MFMA phase of chunk ch and written to LDS after it (register prefetch, single LDS buffer).
+    constexpr int PMAX = 384;                                   // host bound on (R+2)*(CW+2)
+    constexpr int NPV = (PMAX * VPP + 255) / 256;
+    constexpr int WV = KP / VEC;                                // vectors per weight row
+    constexpr int NWV = (NB * WV + 255) / 256;
+    // Out-of-image vectors get a byte offset >= 2^31, beyond the buffer (the launcher keeps x below 2 GiB): the
+    // hardware answers such a buffer load with zeros - the zero padding needs no mask at the LDS write.
+    const unsigned xbytes = (unsigned)a.B * a.IH * a.IW * a.Cin * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xbuf = buffer_of(a.x, xbytes);
+    const unsigned img0 = (unsigned)b * a.IH * a.IW * a.Cin * (unsigned)sizeof(T);
+    unsigned psrc[NPV];                                         // byte offset inside the image, or 0x80000000
+    int pdst[NPV];                                              // byte offset inside the LDS patch
+#pragma unroll
+    for (int j = 0; j < NPV; ++j) {
+        const int i = tid + j * 256;
+        const int px = i / VPP, vv = i % VPP;
+        const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
+        const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
+        const bool ok = i < PPIX * VPP && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+        psrc[j] = ok ? (unsigned)((iy * a.IW + ix) * a.Cin + vv * VEC) * (unsigned)sizeof(T) : 0x80000000u;
+        // vectors beyond the patch go to a per-thread dump slot: the stash is straight-line code (a branch per vector
+        // cut it into 15 basic blocks per chunk, each with its own wait)
+        pdst[j] = i < PPIX * VPP ? py * PROWB + pxx * PXB + vv * 16 : dump + tid * 16;
+    }
+    uint4 pv[NPV], wv[NWV];
+    auto fetch = [&](int ch) {
+        const unsigned base = img0 + (unsigned)(ch * CK) * (unsigned)sizeof(T);
+#pragma unroll
+        for (int j = 0; j < NPV; ++j) pv[j] = buffer_load16(xbuf, psrc[j] + base);
+        const T* wsrc = w + ((long)ch * a.Cout + co0) * KP;     // the chunk's NB rows are contiguous
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
+            const int i = tid + j * 256;
+            wv[j] = *reinterpret_cast<const uint4*>(wsrc + (i < NB * WV ? i : 0) * VEC);
+        }
+    };
+    auto stash = [&](int ch) {
+        float isc[VEC], ish[VEC];                               // XF: this thread's channel vector (256 % VPP == 0)
+        if constexpr (XF) {
+            const float* cs = coefl + ch * CK + (tid % VPP) * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) {
+                *reinterpret_cast<float4*>(isc + e) = *reinterpret_cast<const float4*>(cs + e);
+                *reinterpret_cast<float4*>(ish + e) = *reinterpret_cast<const float4*>(cs + a.Cin + e);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NPV; ++j) {
+            uint4 t = pv[j];
+            if constexpr (XF) t = bn_relu_vec<T>(t, isc, ish);
+            *reinterpret_cast<uint4*>(patch + pdst[j]) = t;
+        }
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
+            const int i = tid + j * 256;
+            const uint4 t = wv[j];
+            if (NB * WV % 256 == 0 || i < NB * WV) *reinterpret_cast<uint4*>(wl + (i / WV) * WROWB + (i % WV) * 16) = t;
+        }
+    };
+    // the first chunk's loads leave before anything else is computed: the fragment decode, the bias and the BST loads
+    // below run under their latency (in-kernel stamps: the un-overlapped first fetch was 9-16 % of a workgroup's life)
+    fetch(0);
     // per-fragment pixel decode.  The tile's fragments of 16 consecutive pixels are dealt to the waves round-robin
     // (fragment f of wave w = fragment 4f + w of the tile) and a wave skips the MFMAs of fragments beyond the tile:
     // the small deep maps fill only part of the 16 slots (10x10: 7, 12x12: 9, 14x14: 13), and dealt in blocks of four
@@ -155,67 +222,6 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
                 yv[f][n] = buffer_load_raw4<T>(bybuf, opix[f] >= 0 ? (unsigned)(opix[f] * a.Cout + co0 + n * 16 + q * 4) *
                                                                        (unsigned)sizeof(T) : ybytes);
     }
-    // ---- staging plan.  Every thread moves up to NPV patch vectors and NWV weight vectors per channel chunk.  The
-    // loads are branch-free (out-of-image / out-of-range lanes read a valid dummy address and are zeroed by a
-    // select) so that all of a chunk's loads are in flight together, and the loads of chunk ch+1 are issued before
-    // the MFMA phase of chunk ch and written to LDS after it (register prefetch, single LDS buffer).
-    constexpr int PMAX = 384;                                   // host bound on (R+2)*(CW+2)
-    constexpr int NPV = (PMAX * VPP + 255) / 256;
-    constexpr int WV = KP / VEC;                                // vectors per weight row
-    constexpr int NWV = (NB * WV + 255) / 256;
-    // Out-of-image vectors get a byte offset >= 2^31, beyond the buffer (the launcher keeps x below 2 GiB): the
-    // hardware answers such a buffer load with zeros - the zero padding needs no mask at the LDS write.
-    const unsigned xbytes = (unsigned)a.B * a.IH * a.IW * a.Cin * (unsigned)sizeof(T);
-    const __amdgpu_buffer_rsrc_t xbuf = buffer_of(a.x, xbytes);
-    const unsigned img0 = (unsigned)b * a.IH * a.IW * a.Cin * (unsigned)sizeof(T);
-    unsigned psrc[NPV];                                         // byte offset inside the image, or 0x80000000
-    int pdst[NPV];                                              // byte offset inside the LDS patch
-#pragma unroll
-    for (int j = 0; j < NPV; ++j) {
-        const int i = tid + j * 256;
-        const int px = i / VPP, vv = i % VPP;
-        const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
-        const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
-        const bool ok = i < PPIX * VPP && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
-        psrc[j] = ok ? (unsigned)((iy * a.IW + ix) * a.Cin + vv * VEC) * (unsigned)sizeof(T) : 0x80000000u;
-        pdst[j] = py * PROWB + pxx * PXB + vv * 16;
-    }
-    uint4 pv[NPV], wv[NWV];
-    auto fetch = [&](int ch) {
-        const unsigned base = img0 + (unsigned)(ch * CK) * (unsigned)sizeof(T);
-#pragma unroll
-        for (int j = 0; j < NPV; ++j) pv[j] = buffer_load16(xbuf, psrc[j] + base);
-        const T* wsrc = w + ((long)ch * a.Cout + co0) * KP;     // the chunk's NB rows are contiguous
-#pragma unroll
-        for (int j = 0; j < NWV; ++j) {
-            const int i = tid + j * 256;
-            wv[j] = *reinterpret_cast<const uint4*>(wsrc + (i < NB * WV ? i : 0) * VEC);
-        }
-    };
-    auto stash = [&](int ch) {
-        float isc[VEC], ish[VEC];                               // XF: this thread's channel vector (256 % VPP == 0)
-        if constexpr (XF) {
-            const float* cs = coefl + ch * CK + (tid % VPP) * VEC;
-#pragma unroll
-            for (int e = 0; e < VEC; e += 4) {
-                *reinterpret_cast<float4*>(isc + e) = *reinterpret_cast<const float4*>(cs + e);
-                *reinterpret_cast<float4*>(ish + e) = *reinterpret_cast<const float4*>(cs + a.Cin + e);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NPV; ++j) {
-            const int i = tid + j * 256;
-            uint4 t = pv[j];   // by value first: a conditional store straight from the array keeps it in scratch
-            if constexpr (XF) t = bn_relu_vec<T>(t, isc, ish);
-            if (i < PPIX * VPP) *reinterpret_cast<uint4*>(patch + pdst[j]) = t;
-        }
-#pragma unroll
-        for (int j = 0; j < NWV; ++j) {
-            const int i = tid + j * 256;
-            const uint4 t = wv[j];
-            if (i < NB * WV) *reinterpret_cast<uint4*>(wl + (i / WV) * WROWB + (i % WV) * 16) = t;
-        }
-    };
     if constexpr (XF) __syncthreads();                          // coefl is read by the first stash
 
     const int nchunks = a.Cin / CK;
@@ -224,7 +230,6 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     auto chunks = [&](auto nf_tag) {
         constexpr int NF = decltype(nf_tag)::value;
         STAMP(1);
-        fetch(0);
         for (int ch = 0; ch < nchunks; ++ch) {
             stash(ch);
             if (ch == 0) STAMP(2);
@@ -598,6 +603,7 @@ size_t igemm_lds(const ConvArgs& a) {
     if (lds < epi) lds = epi;
     lds += (size_t)NBF * 16 * 4;                                                       // resident bias row
     lds += (size_t)2 * a.Cin * 4 + (size_t)4 * NBF * 16 * 4;                           // XF / BST coefficient rows
+    lds += 4096;                                                                       // tile kernel: stash dump slots
     return lds;
 }
 

@@ -60,22 +60,43 @@ USE_PERSISTENT = os.environ.get('VQA_GRU_PERSISTENT', '0') != '0'
 # workgroups (= CUs: one fits per CU) the persistent recurrence may hold; 0 = as many as are resident.  H/16 (one
 # batch slab) is the smallest grid: 64 CUs at H = 1024, the other 192 stay with the CNN.
 PERSISTENT_MAX_WG = int(os.environ.get('VQA_GRU_MAX_WG', '0'))
+# Default recurrence (bf16, H % 64 == 0): ONE launch per time step - the recurrent GEMM streams its operands, kept in
+# MFMA-fragment order, from L2 and applies the gates in its epilogue (csrc/gru_step.hip).  VQA_GRU_FUSED_STEP=0: GEMM + split-K reduce + gate kernel per step.
+FUSED_STEP = os.environ.get('VQA_GRU_FUSED_STEP', '1') != '0'
 
 
 def _persistent_ok(dtype, H):
     return USE_PERSISTENT and dtype == torch.bfloat16 and H % 256 == 0 and 48 * (2 * H + 32) <= 160 * 1024
 
 
+def _fused_ok(dtype, H):
+    return FUSED_STEP and dtype == torch.bfloat16 and H >= 64 and H % 64 == 0
+
+
+def _packed(B, k):
+    """Elements of one fragment-order activation of the fused step kernels (rows padded to whole 64-row groups)."""
+    return -(-B // 64) * 64 * k
+
+
 def _recurrence_fwd(x, E, dtype, w_ih, w_hh, b_ih, b_hh, B, T, allow_persistent=True):
     """x [T*B, >=E] (MFMA dtype, time-major) -> h_f f32 / h_t dtype [T+1,B,H] (slot 0 = h_-1 = 0) and the saved gates."""
     H, dev = w_hh.shape[1], x.device
     wih = ops.cast_pad(w_ih, dtype, ops.pad8(E))             # [3H, E] (row stride padded to 8)
-    whh = ops.cast_pad(w_hh, dtype)
     gi = ops.gemm(x[:, :E], wih, bias=b_ih)                  # [T*B, 3H] fp32
     h_f = torch.zeros(T + 1, B, H, device=dev, dtype=torch.float32)   # h_{-1} = 0, h_0 .. h_{T-1}
     h_t = torch.zeros(T + 1, B, H, device=dev, dtype=dtype)
     save = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
-    if not (allow_persistent and _persistent_ok(dtype, H) and
+    persistent = allow_persistent and _persistent_ok(dtype, H)
+    if not persistent and _fused_ok(dtype, H):
+        # one launch per time step: the recurrent GEMM with the gates in its epilogue, operands in MFMA-fragment order
+        # (csrc/gru_step.hip); W_hh is packed straight from the f32 master
+        wf = torch.empty(3 * H * H, device=dev, dtype=dtype)
+        L.call('vqa_gru_pack_whh', w_hh.contiguous(), H, wf, None)
+        h_p = torch.empty((T + 1) * _packed(B, H), device=dev, dtype=dtype)
+        L.call('vqa_gru_fwd_fused', gi, wf, b_hh, h_f, h_t, h_p, save, B, T, H)
+        return h_f, h_t, save
+    whh = ops.cast_pad(w_hh, dtype)
+    if not (persistent and
             L.fits('vqa_gru_fwd_persistent', gi, whh, whh.stride(0), b_hh, h_f, h_t, save, B, T, H,
                    torch.empty(2, device=dev, dtype=torch.int32), PERSISTENT_MAX_WG)):
         # T x (recurrent GEMM + gate kernel), issued by one call (vqa_gru_fwd_steps: same launches, no per-step
@@ -91,7 +112,6 @@ def _recurrence_bwd(x, E, dtype, h_f, h_t, save, w_ih, w_hh, b_ih, b_hh, dh_last
     """BPTT of one layer.  dh_last [B,H] / dh_seq [T,B,H] (either may be None): gradients w.r.t. the last / every
     step's output.  Returns (dx [T*B,E] f32, dw_ih, dw_hh, db_ih, db_hh)."""
     H, dev = w_hh.shape[1], x.device
-    whh_T = ops.cast_pad(w_hh.t().contiguous(), dtype)       # [H, 3H]
     wih_T = ops.cast_pad(w_ih.t().contiguous(), dtype)       # [E, 3H]
     dgi = torch.empty(T * B, 3 * H, device=dev, dtype=dtype)
     dgh = torch.empty(T * B, 3 * H, device=dev, dtype=dtype)
@@ -102,14 +122,23 @@ def _recurrence_bwd(x, E, dtype, h_f, h_t, save, w_ih, w_hh, b_ih, b_hh, dh_last
         dh = dh_last.contiguous().float()
     else:
         dh = torch.zeros(B, H, device=dev, dtype=torch.float32)
-    if not (dh_seq is None and _persistent_ok(dtype, H) and
-            L.fits('vqa_gru_bwd_persistent', whh_T, whh_T.stride(0), h_f, save, dh, dgi, dgh, B, T, H,
-                   torch.empty(2, device=dev, dtype=torch.int32), PERSISTENT_MAX_WG)):
+    persistent = dh_seq is None and _persistent_ok(dtype, H)
+    if not persistent and _fused_ok(dtype, H):
+        wb = torch.empty(3 * H * H, device=dev, dtype=dtype)
+        L.call('vqa_gru_pack_whh', w_hh.contiguous(), H, None, wb)            # W_hh^T, fragment order
+        dgh_p = torch.empty(2 * _packed(B, 3 * H), device=dev, dtype=dtype)
         dh_ws = torch.empty(2, B, H, device=dev, dtype=torch.float32)
-        splits = ops.gemm_splits(B, H, 3 * H, dtype)
-        ws = torch.empty(splits, B, H, device=dev, dtype=torch.float32) if splits > 1 else None
-        L.call('vqa_gru_bwd_steps', L.dt(x), dh, save, h_f, whh_T, whh_T.stride(0), dgi, dgh, dh_ws, ws, splits,
-               B, T, H, dh_seq)
+        L.call('vqa_gru_bwd_fused', dh, save, h_f, wb, dgi, dgh, dgh_p, dh_ws, B, T, H, dh_seq)
+    else:
+        whh_T = ops.cast_pad(w_hh.t().contiguous(), dtype)   # [H, 3H]
+        if not (persistent and
+                L.fits('vqa_gru_bwd_persistent', whh_T, whh_T.stride(0), h_f, save, dh, dgi, dgh, B, T, H,
+                       torch.empty(2, device=dev, dtype=torch.int32), PERSISTENT_MAX_WG)):
+            dh_ws = torch.empty(2, B, H, device=dev, dtype=torch.float32)
+            splits = ops.gemm_splits(B, H, 3 * H, dtype)
+            ws = torch.empty(splits, B, H, device=dev, dtype=torch.float32) if splits > 1 else None
+            L.call('vqa_gru_bwd_steps', L.dt(x), dh, save, h_f, whh_T, whh_T.stride(0), dgi, dgh, dh_ws, ws, splits,
+                   B, T, H, dh_seq)
     hprev = h_t[:T].reshape(T * B, H)
     # parameter gradients are written into the flat gradient buffer when there is one (ops.grad_dst)
     dw_hh = ops.gemm(dgh, hprev, trans=True, out=ops.grad_dst(w_hh))          # [3H, H]

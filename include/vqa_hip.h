@@ -105,9 +105,12 @@ int vqa_bn_eval_coeffs(void* stream, int C, const float* gamma, const float* bet
 int vqa_bn_eval_coeffs_all(void* stream, int n, const void* const* gamma, const void* const* beta,
                            const void* const* running_mean, const void* const* running_var, const void* const* bias,
                            const int* C, float eps, float* coef, int ldc);
-/* BatchNorm apply + nn.ReLU + nn.MaxPool2d(2,2) / nn.AvgPool2d(2,2) (cnn.py:23-41): pool 0 none, 1 max, 2 avg. */
+/* BatchNorm apply + nn.ReLU + nn.MaxPool2d(2,2) / nn.AvgPool2d(2,2) (cnn.py:23-41): pool 0 none, 1 max, 2 avg.
+ * ysel (may be NULL; max pool only, same shape as a): receives the RAW conv output at the position the pool selects,
+ * so that this layer's BatchNorm-backward sums can be formed at pooled resolution by the data gradient above it
+ * (vqa_conv3x3_fwd with bn_y = ysel).  Status 1 when ysel is asked for a shape the row-staged kernel does not serve. */
 int vqa_bn_act_pool_fwd(void* stream, int dtype, const void* y, void* a, const float* scale, const float* shift,
-                        int B, int H, int W, int C, int pool);
+                        int B, int H, int W, int C, int pool, void* ysel);
 /* Backward of pool + ReLU + BatchNorm (autograd of cnn.py:23-41).  apply = 0: partial sums of dz and dz*xhat into
  * `part` (vqa_bn_bwd_rows() rows of [C][2]); apply = 1: dy = scale*(dz - c1 - xhat*c2). */
 int vqa_bn_bwd_rows(int dtype, int B, int H, int W, int C, int pool);

@@ -386,3 +386,80 @@ def test_encoder_with_fused_bn_backward_matches_separate_pass(prec, monkeypatch)
             assert float(a.norm()) == 0.0
         else:
             assert float((a - b).norm() / b.norm()) < (1e-5 if prec == 'fp32' else 1e-2), k   # (bf16: dy re-rounded)
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('B,c_lo,c_hi,H,W', [(2, 16, 32, 40, 40), (3, 32, 64, 22, 30), (1, 16, 32, 224, 224),
+                                             (2, 64, 128, 12, 16)])
+def test_pooled_bn_backward_sums_from_ysel(prec, B, c_lo, c_hi, H, W):
+    """Max-pooled block below a conv (cnn.py:27-30): the pool pass's second output ysel is the raw y at the position
+    the pool selects (first maximum of z in window order, negative scales included), its `a` is unchanged, and the data
+    gradient above with bn_y = ysel returns rows that, finalized, equal the pooled reduce pass over the full-resolution
+    (y, d) (vqa_bn_bwd apply = 0, pool = 1) up to fp32 summation order."""
+    import ctypes
+    from vqa_amd import _lib as L, cnn as C
+    torch.manual_seed(c_lo + c_hi + H)
+    dt = DT[prec]
+    y = (torch.randn(B, H, W, c_lo) * 1.5).to(dt)
+    y[:, 0:2, 0:2] = y[:, 0:1, 0:1]                                          # a window of ties
+    y = y.cuda()
+    coef = torch.stack([(torch.rand(c_lo) + 0.5) * torch.where(torch.arange(c_lo) % 5 == 0, -1.0, 1.0),
+                        torch.randn(c_lo) * 0.4, torch.randn(c_lo) * 0.3, torch.rand(c_lo) + 0.7]).cuda()
+    a_plain = C.bn_act_pool(y, coef[0], coef[1], 1)
+    a, ysel = C.bn_act_pool(y, coef[0], coef[1], 1, want_ysel=True)
+    assert ysel is not None and torch.equal(a, a_plain)
+    # definition: windows in (0,0), (0,1), (1,0), (1,1) order, first maximum of z
+    yw = torch.stack([y[:, i::2, j::2][:, :H // 2, :W // 2] for i in (0, 1) for j in (0, 1)], 0).float()
+    z = torch.addcmul(coef[1], yw, coef[0])                                  # fma like the kernel
+    first = z.argmax(0, keepdim=True)                                        # torch: first maximum
+    assert torch.equal(ysel.float(), yw.gather(0, first)[0])
+    # upper conv: c_lo -> c_hi, padding 2 (the first conv of the next block), on the pooled map
+    PH, PW = H // 2, W // 2
+    w = torch.randn(c_hi, c_lo, 3, 3) / (3 * c_lo ** 0.5)
+    dy = torch.randn(B, PH + 2, PW + 2, c_hi).to(dt).cuda()
+    wd = C.pack_weights(w.cuda(), c_lo, dt, dgrad=True)
+    d_plain, _ = C.conv_fwd(dy, wd, None, c_lo, 0, False, kind='dgrad')
+    d_fused, rows = C.conv_fwd(dy, wd, None, c_lo, 0, False, kind='dgrad', bst=(ysel, coef))
+    assert torch.equal(d_fused, d_plain) and tuple(d_plain.shape) == (B, PH, PW, c_lo)
+    nrows = L.lib().vqa_bn_bwd_rows(L.dt(y), B, H, W, c_lo, 1)
+    part = torch.empty(nrows, c_lo, 2, device='cuda')
+    L.call('vqa_bn_bwd', L.dt(y), 0, y, d_plain, None, coef[0], coef[1], coef[2], coef[3], None, None, part,
+           B, H, W, c_lo, 1)
+    n = float(B * H * W)
+    out = []
+    for p in (rows, part):
+        dgamma, dbeta, c1, c2 = (torch.empty(c_lo, device='cuda') for _ in range(4))
+        L.check(L.lib().vqa_bn_bwd_finalize(L.stream(), L.ptr(p), p.shape[0], c_lo, ctypes.c_double(n), L.ptr(dgamma),
+                                            L.ptr(dbeta), L.ptr(c1), L.ptr(c2)), 'bn_bwd_finalize')
+        out.append((dgamma.cpu().double(), dbeta.cpu().double()))
+    scale = [max(float(t.abs().max()), 1.0) for t in out[1]]
+    for k in range(2):
+        assert float((out[0][k] - out[1][k]).abs().max()) < 1e-5 * scale[k] * (n ** 0.5)
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_encoder_with_pooled_bn_backward_matches_separate_pass(prec, monkeypatch):
+    """Whole encoder, cnn.FUSE_POOL_BWD off / 16 (the 224x224 block only) / 32 (also through the multi-chunk data
+    gradient) / 128 (every pooled block with a conv above it: the default): forward identical; gradients equal up to the
+    fp32 summation order of the sums."""
+    from vqa_amd import cnn as M, synth
+    sd = {k[4:]: v for k, v in synth.state_dict(42, 64, 50, 30).items() if k.startswith('cnn.')}
+    img = synth.images(9, 3, 224).cuda()
+    outs = []
+    for fuse in (0, 16, 32, 128):
+        monkeypatch.setattr(M, 'FUSE_POOL_BWD', fuse)
+        m = M.CNN(2, 'max', precision=prec)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        out = m(img)
+        torch.manual_seed(1)
+        (out * torch.rand_like(out)).sum().backward()
+        outs.append((out.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0])
+        for k in o[1]:
+            a, b = o[1][k].double(), outs[0][1][k].double()
+            if float(b.norm()) == 0.0:
+                assert float(a.norm()) == 0.0
+            else:
+                assert float((a - b).norm() / b.norm()) < (1e-5 if prec == 'fp32' else 1e-2), k

@@ -71,11 +71,11 @@ def call(name, *args):
         raise VqaHipError(f'{name} failed with status {status}', status)
 
 
-def fits(name, *args):
+def fits(name, *args, **kw):
     """call() for the entry points that document status 1 as "this shape is not mine, use the general path" (the
     persistent recurrence): False on status 1 (nothing was launched), True on success, raises on anything else."""
     try:
-        call(name, *args)
+        call(name, *args, **kw)
     except VqaHipError as e:
         if len(e.args) > 1 and e.args[1] == 1:
             return False

@@ -170,12 +170,19 @@ def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None):
     return dw
 
 
-def bn_act_pool(y, scale, shift, pool):
+def bn_act_pool(y, scale, shift, pool, want_ysel=False):
+    """a = pool(relu(scale * y + shift)).  want_ysel (max pool): returns (a, ysel), ysel = the raw y at the selected
+    position of every window (None when the shape is not served - the caller then runs the reduce pass)."""
     B, H, W, C = y.shape
     a = torch.empty(B, H // 2 if pool else H, W // 2 if pool else W, C, device=y.device, dtype=y.dtype)
     tag = lambda: dict(kind='fwd', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((y.numel() + a.numel()) * y.element_size()))
-    L.call('vqa_bn_act_pool_fwd', L.dt(y), y, a, scale, shift, B, H, W, C, pool, tag=tag)
-    return a
+    if want_ysel and pool == 1:
+        ysel = torch.empty_like(a)
+        tag2 = lambda: dict(tag(), bytes=tag()['bytes'] + a.numel() * y.element_size())
+        if L.fits('vqa_bn_act_pool_fwd', L.dt(y), y, a, scale, shift, B, H, W, C, pool, ysel, tag=tag2):
+            return a, ysel
+    L.call('vqa_bn_act_pool_fwd', L.dt(y), y, a, scale, shift, B, H, W, C, pool, None, tag=tag)
+    return (a, None) if want_ysel else a
 
 
 def to_nhwc(images, dtype):
@@ -250,7 +257,7 @@ def first_wgrad(images, dy, pad, out=None, mirror=False, bn=None):
 
 
 def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False, wpk=None, mirror=False,
-              in_coeffs=None, apply=True):
+              in_coeffs=None, apply=True, want_ysel=False):
     """conv3x3 -> BatchNorm -> ReLU -> (pool).  x NHWC (first=True: the NCHW image, dedicated kernel).  Returns
     (a, saved) with saved = (x, y, scale, shift, mean, invstd) for block_bwd.
     in_coeffs: x is the raw conv output of the previous block, whose BatchNorm + ReLU this block's conv applies itself.
@@ -272,6 +279,9 @@ def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False,
                 'vqa_bn_finalize')
     else:
         L.call('vqa_bn_eval_coeffs', cout, gamma, beta, rm, rv, BN_EPS, scale, shift)
+    if want_ysel:
+        a, ysel = bn_act_pool(y, scale, shift, pool, want_ysel=True)
+        return a, (x, y, scale, shift, mean, invstd), ysel
     a = bn_act_pool(y, scale, shift, pool) if apply else None
     return a, (x, y, scale, shift, mean, invstd)
 
@@ -416,6 +426,11 @@ FUSE_BN_FWD = os.environ.get('VQA_FUSE_BN_FWD', '1') != '0'
 # traffic less); in the multi-chunk kernel the extra reads cost more than the pass (58x58x64: +0.10 ms for 0.046).
 FUSE_BN_BWD = int(os.environ.get('VQA_FUSE_BN_BWD', '32'))      # largest channel count it is applied to; 0 = never
 FUSE_FIRST_BN = os.environ.get('VQA_FUSE_FIRST_BN', '1') != '0'
+# The same for a MAX-POOLED block below: its forward pool pass also stores ysel, the raw conv output at the position each
+# window selects (pooled resolution), and the data gradient above forms the BatchNorm-backward sums from (d, ysel) - the
+# reduce pass over the full-resolution y (4x the bytes) never runs.  Largest channel count of the pooled layer it is
+# applied to; 0 = never.
+FUSE_POOL_BWD = int(os.environ.get('VQA_FUSE_POOL_BWD', '128'))
 _WGRAD_STREAMS = {}
 
 
@@ -441,7 +456,7 @@ class _CnnFunction(torch.autograd.Function):
         if not training:
             ctx.cfg = cfg
             return _eval_forward(x, first, params, buffers, padding, pool_mode, dtype)
-        saved, meta = [], []
+        saved, meta, ysels = [], [], [None] * 10
         # every packed weight slab of the step (forward, and data-gradient when training) in one launch
         cinp = [CIN0_PAD] + list(CHANNELS[1:10])
         fjobs = [(params[4 * li], cinp[li], False) for li in range(10) if not (first and li == 0)]
@@ -455,13 +470,21 @@ class _CnnFunction(torch.autograd.Function):
             pad = padding if li in (0, 2, 4, 6) else 0
             pool = pool_mode if li % 2 == 1 else 0
             defer = FUSE_BN_FWD and pool == 0 and li < 9        # the next conv (pad 0) applies this block's BN + ReLU
-            a, sv = block_fwd(x, w, bias, gamma, beta, buffers[2 * li], buffers[2 * li + 1], pad, pool, training,
-                              first=first and li == 0, wpk=wf[li], mirror=mirror and li == 0, in_coeffs=in_coeffs,
-                              apply=not defer)
+            # (the pooled layer's channels are the output channels of the data gradient above it)
+            ysel_ok = pool == 1 and li < 9 and CHANNELS[li + 1] <= FUSE_POOL_BWD
+            if ysel_ok:
+                a, sv, ysels[li] = block_fwd(x, w, bias, gamma, beta, buffers[2 * li], buffers[2 * li + 1], pad, pool,
+                                             training, first=first and li == 0, wpk=wf[li], mirror=mirror and li == 0,
+                                             in_coeffs=in_coeffs, want_ysel=True)
+            else:
+                a, sv = block_fwd(x, w, bias, gamma, beta, buffers[2 * li], buffers[2 * li + 1], pad, pool, training,
+                                  first=first and li == 0, wpk=wf[li], mirror=mirror and li == 0, in_coeffs=in_coeffs,
+                                  apply=not defer)
             saved += list(sv)
             meta.append((pad, pool, in_coeffs is not None))
             x, in_coeffs = (sv[1], (sv[2], sv[3])) if defer else (a, None)
-        ctx.save_for_backward(*saved, *params)
+        ctx.ysel_at = [li for li in range(10) if ysels[li] is not None]
+        ctx.save_for_backward(*saved, *params, *[ysels[li] for li in ctx.ysel_at])
         ctx.meta, ctx.cfg, ctx.first, ctx.mirror = meta, cfg, first, mirror
         B, PH, PW, C = x.shape
         return x.reshape(B, PH * PW, C).float()
@@ -471,7 +494,8 @@ class _CnnFunction(torch.autograd.Function):
         padding, pool_mode, training, dtype, _ = ctx.cfg
         if not training:
             raise L.VqaHipError('CNN backward is implemented for training-mode BatchNorm only')
-        saved, params = ctx.saved_tensors[:60], ctx.saved_tensors[60:]
+        saved, params = ctx.saved_tensors[:60], ctx.saved_tensors[60:100]
+        ysels = dict(zip(ctx.ysel_at, ctx.saved_tensors[100:]))
         grads = [None] * 40
         B, H, W, C = saved[55].shape
         pool_last = ctx.meta[9][1]
@@ -484,6 +508,8 @@ class _CnnFunction(torch.autograd.Function):
             bst = None
             if li > 0 and ctx.meta[li - 1][1] == 0 and CHANNELS[li] <= min(FUSE_BN_BWD, _ck(CHANNELS[li], dtype)):
                 bst = (saved[6 * (li - 1) + 1], coef_block(*saved[6 * (li - 1) + 2: 6 * (li - 1) + 6]))
+            elif li - 1 in ysels:       # max-pooled block below: the same sums from (d, ysel) at pooled resolution
+                bst = (ysels[li - 1], coef_block(*saved[6 * (li - 1) + 2: 6 * (li - 1) + 6]))
             # fused_in: this layer's input x is the previous layer's raw conv output; its weight gradient re-applies
             # that layer's BatchNorm + ReLU (saved scale / shift) as the forward conv did
             in_coeffs = (saved[6 * (li - 1) + 2], saved[6 * (li - 1) + 3]) if fused_in else None

@@ -209,10 +209,15 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd(const T* __restrict__ y, 
 // 0.040.  (The same staging for the backward reduce pass measured slower: its workgroups loop over several rows to
 // keep the number of partial-sum rows down, and the barriers of that loop cost more than the access pattern gains; for
 // the backward apply pass, load -> barrier -> dy in place -> barrier -> store per row pair: 224x224x16 0.168 -> 0.189.)
-template <typename T, int POOL, bool NT>
+// YS (max pool): also writes ysel = the RAW conv output at the position the pool selects (the first maximum of z in
+// window order - the position bn_bwd routes the gradient to), pooled resolution.  With it the BatchNorm-backward sums of
+// this layer, dz = d * 1[scale * ysel + shift > 0] and dz * xhat(ysel), need only pooled-resolution tensors: the data
+// gradient that produces d forms them in its epilogue (conv.hip BST with bn_y = ysel) and the reduce pass over the
+// full-resolution y (4x the bytes) never runs.
+template <typename T, int POOL, bool NT, bool YS = false>
 __global__ __launch_bounds__(256) void bn_pool_rows_fwd(const T* __restrict__ y, T* __restrict__ a,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                                        int PH, int H, int W, int C) {
+                                                        int PH, int H, int W, int C, T* __restrict__ ysel = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using S = Stream<T, NT>;
     constexpr int N = S::N;
@@ -245,6 +250,25 @@ __global__ __launch_bounds__(256) void bn_pool_rows_fwd(const T* __restrict__ y,
     for (int o = threadIdx.x; o < PW * CV; o += 256) {          // 256 % CV == 0: o % CV == cv
         const int pw = o / CV;
         float acc[N];
+        if constexpr (YS) {
+            static_assert(!YS || POOL == 1, "ysel: max pool");
+            float bz[N], by[N];                                 // best z so far and the y it came from
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const v4u raw = lds[((k >> 1) * W + 2 * pw + (k & 1)) * CV + cv];
+                const T* el = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    const float yv = to_f32(el[e]), z = fmaf(yv, sc[e], sh[e]);
+                    const bool better = k == 0 || z > bz[e];    // strict: the FIRST maximum keeps its place
+                    bz[e] = better ? z : bz[e];
+                    by[e] = better ? yv : by[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < N; ++e) acc[e] = fmaxf(bz[e], 0.f);
+            S::store(ysel + ((long)(b * PH + ph) * PW) * C + (long)o * N, by);
+        } else {
 #pragma unroll
         for (int e = 0; e < N; ++e) acc[e] = 0.f;               // relu floor; for avg: running sum
 #pragma unroll
@@ -256,6 +280,7 @@ __global__ __launch_bounds__(256) void bn_pool_rows_fwd(const T* __restrict__ y,
                 const float z = fmaxf(fmaf(to_f32(el[e]), sc[e], sh[e]), 0.f);
                 acc[e] = POOL == 1 ? fmaxf(acc[e], z) : acc[e] + z;
             }
+        }
         }
         if (POOL == 2) {
 #pragma unroll
@@ -473,7 +498,7 @@ static bool use_nt(double bytes) { return bytes > 256e6; }
 constexpr int kReduceRows = 4096;   // 2048: reduce pass 3 % slower, 16384: 8 % slower (more partial rows to finalize)
 
 extern "C" int vqa_bn_act_pool_fwd(void* stream, int dtype, const void* y, void* a, const float* scale,
-                                   const float* shift, int B, int H, int W, int C, int pool) {
+                                   const float* shift, int B, int H, int W, int C, int pool, void* ysel) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (pool < 0 || pool > 2 || (dtype != VQA_BF16 && dtype != VQA_F32)) return VQA_ERR_ARG;
     const int N = dtype == VQA_BF16 ? 8 : 4, esz = 16 / N;
@@ -484,6 +509,18 @@ extern "C" int vqa_bn_act_pool_fwd(void* stream, int dtype, const void* y, void*
     const int U = pool ? kFwdPoolU : kFwdU, passes = 1;
     const bool nt = use_nt(((double)B * H * W * C + (double)out_px * C) * esz);
     const size_t row_pair = (size_t)2 * W * C * esz;
+    if (ysel && !(pool == 1 && row_pair <= 64 * 1024 && H >= 2 && W >= 2)) return VQA_ERR_ARG;   // (rows kernel only)
+    if (ysel) {
+        const dim3 rgrid((unsigned)(B * (H / 2)));
+#define GY(T, NT) hipLaunchKernelGGL((bn_pool_rows_fwd<T, 1, NT, true>), rgrid, dim3(256), row_pair, s,          \
+                                     static_cast<const T*>(y), static_cast<T*>(a), scale, shift, H / 2, H, W, C, \
+                                     static_cast<T*>(ysel))
+        if (dtype == VQA_BF16) { if (nt) GY(bf16, true); else GY(bf16, false); }
+        else { if (nt) GY(float, true); else GY(float, false); }
+#undef GY
+        CHECK_LAUNCH();
+        return VQA_OK;
+    }
     if (pool && row_pair <= 64 * 1024 && H >= 2 && W >= 2) {
         const dim3 rgrid((unsigned)(B * (H / 2)));
 #define GR(T, P, NT) hipLaunchKernelGGL((bn_pool_rows_fwd<T, P, NT>), rgrid, dim3(256), row_pair, s, \

@@ -52,7 +52,9 @@ __device__ __forceinline__ uint4 load_row_chunk(const T* base, long row, int ld,
 
 
 // bias / row-broadcast add / ReLU / accumulate, then a 4-wide store of C (and the optional bf16 copy C2)
-template <typename TC>
+// RICH: the SELU (act 3) and sigmoid-BCE (act 2) epilogues are compiled into their own instantiations - carried by
+// every kernel they cost the 128 x 128 tile 272 bytes of scratch per lane (3072 x 1024 x 3584 TN: 76 -> 150 us)
+template <typename TC, bool RICH = true>
 __device__ __forceinline__ float epilogue_store(const GemmArgs& g, TC* C, int m, int n, const f32x4& a, bool vec_ok) {
     float v[4], loss = 0.f;
 #pragma unroll
@@ -62,9 +64,10 @@ __device__ __forceinline__ float epilogue_store(const GemmArgs& g, TC* C, int m,
         if (ne < g.N) {
             if (g.bias) x += g.bias[ne];
             if (g.rowadd) x += g.rowadd[(long)(m / g.rowadd_group) * g.N + ne];
-            if (g.act == 1 || g.act == 3) x = act_apply(x, g.act);
+            if (RICH) { if (g.act == 1 || g.act == 3) x = act_apply(x, g.act); }
+            else if (g.act == 1) x = fmaxf(x, 0.f);
             if (g.accumulate) x += to_f32(C[(long)m * g.ldc + ne]);
-            if (g.act == 2) {                      // the arithmetic of bce_partial (misc.hip), element for element
+            if (RICH && g.act == 2) {              // the arithmetic of bce_partial (misc.hip), element for element
                 const float t = g.target ? g.target[(long)m * g.ldt + ne] : 0.f;
                 const float ex = __expf(-fabsf(x));
                 loss += fmaxf(x, 0.f) - x * t + log1pf(ex);
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // NPRE > 1 (small-M problems: a few hundred workgroups, each a short chain of stages): the loads of NPRE stages are
 // issued into registers at once and consumed stage by stage - one memory latency per NPRE stages instead of one per
 // stage, which is what a 256 x 1024 x 1024 GEMM spends its 13 us on.
-template <bool TN, int TM, int TNT, int BK, typename TC, int NPRE = 1>
+template <bool TN, int TM, int TNT, int BK, typename TC, int NPRE = 1, bool RICH = false>
 __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
     constexpr int BM_ = 32 * TM, BN_ = 32 * TNT;
     constexpr int RA = TN ? BM_ * 2 + 32 : BK * 2 + 32, RB = TN ? BN_ * 2 + 32 : BK * 2 + 32;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
     TC* C = static_cast<TC*>(g.C);
     const bool vec_ok = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                         (g.C2 == nullptr || (g.ldc2 % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C2) & 7) == 0));
-    if (vec_ok && n0 + BN_ <= g.N && (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0 && g.act != 2) {
+    if (vec_ok && n0 + BN_ <= g.N && (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0 && !(RICH && g.act == 2)) {
         // Whole-tile case: after the MFMAs a lane owns 4 consecutive n of ONE m, so a store instruction would scatter
         // 16 rows x 32- or 64-byte pieces.  Each wave passes its 16 m x (TNT*16) n block through LDS (free after the
         // loop's last barrier) and writes whole row segments: 128 (bf16) or 256 (f32) contiguous bytes per row.
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
                     if (g.act == 1) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    } else if (g.act == 3) {
+                    } else if (RICH && g.act == 3) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = selu_f(v[e]);
                     }
@@ -415,10 +418,10 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
         for (int j = 0; j < TNT; ++j) {
             const int n = n0 + (wn * TNT + j) * 16 + q * 4;
             if (n >= g.N) continue;
-            lsum += epilogue_store<TC>(g, C, m, n, acc[i][j], vec_ok);
+            lsum += epilogue_store<TC, RICH>(g, C, m, n, acc[i][j], vec_ok);
         }
     }
-    if (g.act == 2) bce_block_partial(g, lsum, reinterpret_cast<double*>(dl));
+    if (RICH && g.act == 2) bce_block_partial(g, lsum, reinterpret_cast<double*>(dl));
 }
 
 // C = epilogue(sum_z ws[z]) in fixed slice order.  VEC4: four consecutive columns per thread (N, ldc, ldc2 multiples
@@ -469,12 +472,12 @@ __global__ void gemm_splitk_reduce(GemmArgs g, int splits) {
     }
 }
 
-template <bool TN, int TM, int TNT, int BK, typename TC, int NPRE = 1>
+template <bool TN, int TM, int TNT, int BK, typename TC, int NPRE = 1, bool RICH = false>
 void launch_bf16(hipStream_t s, const GemmArgs& g, int splits) {
     constexpr int BM_ = 32 * TM, BN_ = 32 * TNT;
     constexpr int lds = 2 * ((TN ? BK : BM_) * (TN ? BM_ * 2 + 32 : BK * 2 + 32) +
                              (TN ? BK : BN_) * (TN ? BN_ * 2 + 32 : BK * 2 + 32));
-    auto k = gemm_bf16<TN, TM, TNT, BK, TC, NPRE>;
+    auto k = gemm_bf16<TN, TM, TNT, BK, TC, NPRE, RICH>;
     if constexpr (lds > 64 * 1024) {
         static bool attr_set[64] = {};   // per device (the attribute lives on the device's copy of the function);
         int dev = 0;                     // benign race: setting it twice is idempotent
@@ -495,13 +498,18 @@ int launch(hipStream_t s, int trans, const GemmArgs& g, int splits) {
         const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
         // small-M NT problems (the head's and the GRU's M = 256 GEMMs): 32x32 tiles, eight stages of loads in flight
         const long small = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
+        const bool rich = g.act >= 2;                                 // SELU / sigmoid-BCE epilogue (NT only)
+        if (rich && trans) return VQA_ERR_ARG;
         if (!trans && splits == 1 && small <= 256 && g.K <= 1024) {   // (one workgroup per CU, one round of loads)
-            launch_bf16<false, 1, 1, 128, TC, 8>(s, g, splits);
+            if (rich) launch_bf16<false, 1, 1, 128, TC, 8, true>(s, g, splits);
+            else launch_bf16<false, 1, 1, 128, TC, 8>(s, g, splits);
         } else if (splits == 1 && big >= 160) {
             if (trans) launch_bf16<true, 4, 4, 64, TC>(s, g, splits);
+            else if (rich) launch_bf16<false, 4, 4, 64, TC, 1, true>(s, g, splits);
             else launch_bf16<false, 4, 4, 64, TC>(s, g, splits);
         } else {
             if (trans) launch_bf16<true, 2, 2, 128, TC>(s, g, splits);
+            else if (rich) launch_bf16<false, 2, 2, 128, TC, 1, true>(s, g, splits);
             else launch_bf16<false, 2, 2, 128, TC>(s, g, splits);
         }
     } else {

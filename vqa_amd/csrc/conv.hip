@@ -366,11 +366,11 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
 // tile is computed once per workgroup (fragment pixel decode, patch vector coordinates), the weight slab and the bias
 // stay resident in LDS, the next tile's patch is prefetched into registers during the MFMAs, and the BatchNorm
 // partial sums stay in registers across tiles: ONE statistics row per workgroup.
-// (the BST form of the 32-channel kernel is held to the three waves per SIMD its plain form has: left alone the
-// compiler spends 217 registers on it)
+// (the BST form of the 32-channel kernel: held to three waves per SIMD - 168 registers, what its plain form has - it
+// spills 52 bytes per lane; at two waves per SIMD it does not, and the 114x114 32->32 data gradient is 4 % faster)
 template <typename T, int CK, int NBF, int VAR>
 #ifndef VQA_BST_WAVES
-#define VQA_BST_WAVES 3
+#define VQA_BST_WAVES 2
 #endif
 __global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) void conv3x3_igemm_p(ConvArgs a) {
     constexpr bool XF = VAR == 1, BST = VAR == 2;

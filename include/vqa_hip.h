@@ -84,11 +84,16 @@ int vqa_conv3x3_first_wgrad_bn(void* stream, int in_dtype, const void* images, c
                                int OH, int OW, int pad, int R, int CW, int flip);
 
 /* Conv2d weight gradient (autograd of cnn.py:23-40): dw [Cout][Cin_real][3][3] f32 = sum over pixels of dy (x) x.
- * `part` is a [G][Cout][9][Cin] f32 workspace (one partial slab per workgroup group, summed in fixed order).
+ * `part` is a [G][Cout][9][Cin] f32 workspace (one partial slab per workgroup group, summed in fixed order; with
+ * dw == NULL the sum is left to vqa_conv3x3_wgrad_reduce_all).
  * in_scale / in_shift: as in vqa_conv3x3_fwd (x = the previous conv's raw output, pad == 0). */
 int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const void* dy, float* part, float* dw, int G, int B,
                       int IH, int IW, int Cin, int Cin_real, int OH, int OW, int Cout, int pad, int R, int CW,
                       const float* in_scale, const float* in_shift);
+/* dw == NULL in vqa_conv3x3_wgrad: the partial slabs are left in `part` and this call reduces the slabs of n layers in
+ * ONE launch (nine dependent little launches per training step otherwise).  part / dw: host arrays of n device
+ * pointers; desc: host array of n x 4 ints (G, Cout, Cin, Cin_real).  Same sums in the same order per output. */
+int vqa_conv3x3_wgrad_reduce_all(void* stream, int n, const void* const* part, void* const* dw, const int* desc);
 
 /* nn.BatchNorm2d training statistics (cnn.py:23-40; eps 1e-5, momentum 0.1): from the conv partials to mean,
  * invstd, scale = gamma*invstd, shift = beta - mean*scale; running_mean / running_var updated in place

@@ -463,3 +463,28 @@ def test_encoder_with_pooled_bn_backward_matches_separate_pass(prec, monkeypatch
                 assert float(a.norm()) == 0.0
             else:
                 assert float((a - b).norm() / b.norm()) < (1e-5 if prec == 'fp32' else 1e-2), k
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('streams', [True, False])
+def test_deferred_weight_gradient_reduction_is_bit_identical(prec, streams, monkeypatch):
+    """cnn.DEFER_WGRAD_REDUCE (opt-in): the nine weight gradients leave their partial slabs and ONE launch
+    (vqa_conv3x3_wgrad_reduce_all) sums them at the end of the backward - the same sums in the same order as a reduce
+    per layer, with and without the weight-gradient stream."""
+    from vqa_amd import cnn as M, synth
+    sd = {k[4:]: v for k, v in synth.state_dict(42, 64, 50, 30).items() if k.startswith('cnn.')}
+    img = synth.images(9, 3, 224).cuda()
+    monkeypatch.setattr(M, 'WGRAD_STREAM', streams)
+    outs = []
+    for defer in (True, False):
+        monkeypatch.setattr(M, 'DEFER_WGRAD_REDUCE', defer)
+        m = M.CNN(2, 'max', precision=prec)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        out = m(img)
+        torch.manual_seed(1)
+        (out * torch.rand_like(out)).sum().backward()
+        torch.cuda.synchronize()
+        outs.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k

@@ -143,7 +143,9 @@ def _plan(*key):
     return _plans[key]
 
 
-def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None):
+def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None, defer=None):
+    """defer (a list): the partial slabs are left unreduced and (part, dw, G, cout, cin, cin_real) is appended to it
+    for wgrad_reduce_all - one launch for all layers at the end of the backward."""
     B, IH, IW, cin = x.shape
     _, OH, OW, cout = dy.shape
     mt = 256 if x.dtype == torch.bfloat16 else 128
@@ -165,9 +167,24 @@ def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None):
     dw = out if out is not None else torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)
     tag = lambda: _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4)
     isc, ish = in_coeffs if in_coeffs is not None else (None, None)
-    L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw, G, B, IH, IW, cin, cin_real, OH, OW, cout, pad, R, CW,
-           isc, ish, tag=tag)
+    L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw if defer is None else None, G, B, IH, IW, cin, cin_real,
+           OH, OW, cout, pad, R, CW, isc, ish, tag=tag)
+    if defer is not None:
+        defer.append((part, dw, G, cout, cin, cin_real))
     return dw
+
+
+def wgrad_reduce_all(jobs):
+    """The deferred reductions of conv_wgrad(defer=jobs), one launch."""
+    if not jobs:
+        return
+    ct, n = L.ctypes, len(jobs)
+    desc = []
+    for _, _, G, cout, cin, cin_real in jobs:
+        desc += [G, cout, cin, cin_real]
+    L.check(L.lib().vqa_conv3x3_wgrad_reduce_all(L.stream(), n, (ct.c_void_p * n)(*[j[0].data_ptr() for j in jobs]),
+                                                 (ct.c_void_p * n)(*[j[1].data_ptr() for j in jobs]),
+                                                 (ct.c_int * (4 * n))(*desc)), 'vqa_conv3x3_wgrad_reduce_all')
 
 
 def bn_act_pool(y, scale, shift, pool, want_ysel=False):
@@ -294,7 +311,7 @@ def coef_block(scale, shift, mean, invstd):
 
 
 def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None, params=None, mirror=False,
-              side=None, in_coeffs=None, part=None, bst=None):
+              side=None, in_coeffs=None, part=None, bst=None, defer=None):
     """d = gradient w.r.t. the block output (NHWC, activation dtype).  Returns (dx, dw, dbias, dgamma, dbeta, below).
     side: HIP stream for the weight gradient (off the dgrad -> BatchNorm-backward chain), None = current stream.
     part: this block's BatchNorm-backward partial sums, already produced by the data gradient of the block above.
@@ -343,7 +360,7 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
     L.call('vqa_bn_bwd', L.dt(y), 1, y, d, dy, scale, shift, mean, invstd, c1, c2, None, B, H, W, C, pool, tag=tag)
     def wgrad():
         return (first_wgrad(x, dy, pad, out=dw_out, mirror=mirror) if first
-                else conv_wgrad(x, dy, cin_real, pad, out=dw_out, in_coeffs=in_coeffs))
+                else conv_wgrad(x, dy, cin_real, pad, out=dw_out, in_coeffs=in_coeffs, defer=defer))
 
     def dgrad():
         if not need_dx:
@@ -431,6 +448,11 @@ FUSE_FIRST_BN = os.environ.get('VQA_FUSE_FIRST_BN', '1') != '0'
 # reduce pass over the full-resolution y (4x the bytes) never runs.  Largest channel count of the pooled layer it is
 # applied to; 0 = never.
 FUSE_POOL_BWD = int(os.environ.get('VQA_FUSE_POOL_BWD', '128'))
+# VQA_DEFER_WGRAD_REDUCE=1: every layer's weight gradient leaves its partial slabs unreduced and one launch at the end of
+# the backward sums them all (vqa_conv3x3_wgrad_reduce_all) instead of nine little launches.  Off by default: 0.1 ms less
+# kernel time per step, but the one launch sits in the step's tail where nothing overlaps it, while the nine run under
+# the data-gradient chain (same-box A/B: 4.402 vs 4.378 ms/step).  Bit-identical either way.
+DEFER_WGRAD_REDUCE = os.environ.get('VQA_DEFER_WGRAD_REDUCE', '0') != '0'
 _WGRAD_STREAMS = {}
 
 
@@ -502,6 +524,7 @@ class _CnnFunction(torch.autograd.Function):
         d = dout.reshape(B, H // 2 if pool_last else H, W // 2 if pool_last else W, C).to(dtype).contiguous()
         side = _wgrad_stream(dout.device) if WGRAD_STREAM else None
         part = None
+        deferred = [] if DEFER_WGRAD_REDUCE else None      # weight-gradient slabs, reduced by one launch at the end
         for li in range(9, -1, -1):
             pad, pool, fused_in = ctx.meta[li]
             # the block below has no pool: this block's data gradient can also do its BatchNorm-backward reduction
@@ -517,10 +540,14 @@ class _CnnFunction(torch.autograd.Function):
                                                  li > 0, first=ctx.first and li == 0, wpk_d=ctx.wd[li],
                                                  mirror=ctx.mirror and li == 0,
                                                  params=params[4 * li: 4 * li + 4], side=side, in_coeffs=in_coeffs,
-                                                 part=part, bst=bst)
+                                                 part=part, bst=bst, defer=deferred)
             grads[4 * li: 4 * li + 4] = [dw, db, dg, dbt]
         if side is not None:
+            with torch.cuda.stream(side):
+                wgrad_reduce_all(deferred)
             torch.cuda.current_stream().wait_stream(side)
+        else:
+            wgrad_reduce_all(deferred)
         return (None, None, *grads, *([None] * 20))
 
 

@@ -944,6 +944,60 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce(const float* part, f
     }
 }
 
+// The same sums for SEVERAL layers in one launch (blockIdx.y = job): every layer's weight gradient leaves its partial
+// slabs behind and one launch at the end of the backward reduces them all - nine dependent little launches (6-12 us
+// each, 98 us per step) become one.  Partial lanes per output group (TPO) are a per-job run-time value here.
+constexpr int RED_MAX_JOBS = 16;
+struct ReduceJobs {
+    const float* part[RED_MAX_JOBS];
+    float* dw[RED_MAX_JOBS];
+    int G[RED_MAX_JOBS], Cout[RED_MAX_JOBS], Cin[RED_MAX_JOBS], Cin_real[RED_MAX_JOBS], tpo[RED_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_all(ReduceJobs j) {
+    __shared__ float4 red[256];
+    const int b = blockIdx.y;
+    const float* part = j.part[b];
+    const int G = j.G[b], Cout = j.Cout[b], Cin = j.Cin[b], Cin_real = j.Cin_real[b], TPO = j.tpo[b];
+    const int OL = 256 / TPO, OPB = OL * 4;
+    const int n = Cout * 9 * Cin;
+    if ((long)blockIdx.x * OPB >= n) return;                // (uniform: before any barrier)
+    const int ol = threadIdx.x % OL, gl = threadIdx.x / OL;
+    const int i = blockIdx.x * OPB + ol * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        const float* p = part + i;
+        int g = gl;
+        for (; g + 3 * TPO < G; g += 4 * TPO) {             // 4 independent loads in flight
+            const float4 a0 = *reinterpret_cast<const float4*>(p + (long)g * n);
+            const float4 a1 = *reinterpret_cast<const float4*>(p + (long)(g + TPO) * n);
+            const float4 a2 = *reinterpret_cast<const float4*>(p + (long)(g + 2 * TPO) * n);
+            const float4 a3 = *reinterpret_cast<const float4*>(p + (long)(g + 3 * TPO) * n);
+            s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
+            s.x += a1.x; s.y += a1.y; s.z += a1.z; s.w += a1.w;
+            s.x += a2.x; s.y += a2.y; s.z += a2.z; s.w += a2.w;
+            s.x += a3.x; s.y += a3.y; s.z += a3.z; s.w += a3.w;
+        }
+        for (; g < G; g += TPO) {
+            const float4 a0 = *reinterpret_cast<const float4*>(p + (long)g * n);
+            s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (gl == 0 && i < n) {
+        for (int k = 1; k < TPO; ++k) {
+            const float4 t = red[k * OL + ol];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        const float v[4] = {s.x, s.y, s.z, s.w};
+        const int ci0 = i % Cin, tp = (i / Cin) % 9, co = i / (9 * Cin);
+        float* dw = j.dw[b];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (ci0 + e < Cin_real) dw[((long)co * Cin_real + ci0 + e) * 9 + tp] = v[e];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- packing
 // w [Cout][Cin][3][3] f32 -> fwd slab  [CinP/CK][Cout][KP],  k = tap*CK + c, ci = chunk*CK + c
 //                         -> dgrad slab [Cout/CKd][CinOut][KPd], k = tap'*CKd + c, co = chunk*CKd + c,
@@ -1127,6 +1181,7 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
 #undef GO_XF
     }
     if (status != VQA_OK) return status;
+    if (!dw) return VQA_OK;                     // the caller reduces the slabs later (vqa_conv3x3_wgrad_reduce_all)
     const int n = Cout * 9 * Cin;
     if (n >= 524288 || G <= 4)
         hipLaunchKernelGGL(conv3x3_wgrad_reduce<4>, dim3((n + 255) / 256), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
@@ -1134,6 +1189,29 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
         hipLaunchKernelGGL(conv3x3_wgrad_reduce<16>, dim3((n + 63) / 64), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
     else
         hipLaunchKernelGGL(conv3x3_wgrad_reduce<64>, dim3((n + 15) / 16), dim3(256), 0, s, part, dw, G, Cout, Cin, Cin_real);
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+// n jobs; part / dw are HOST arrays of device pointers, desc a host array of n x 4 ints (G, Cout, Cin, Cin_real): the
+// reductions n vqa_conv3x3_wgrad calls with dw == NULL left undone, in one launch (same sums, same order per output).
+extern "C" int vqa_conv3x3_wgrad_reduce_all(void* stream, int n, const void* const* part, void* const* dw,
+                                            const int* desc) {
+    if (n < 1 || n > RED_MAX_JOBS || !part || !dw || !desc) return VQA_ERR_ARG;
+    ReduceJobs j;
+    int gx = 1;
+    for (int i = 0; i < n; ++i) {
+        const int* d = desc + 4 * i;
+        if (!part[i] || !dw[i] || d[0] < 1 || d[1] < 1 || d[2] < 1 || d[3] < 1 || d[3] > d[2] || d[2] % 4) return VQA_ERR_ARG;
+        j.part[i] = static_cast<const float*>(part[i]);
+        j.dw[i] = static_cast<float*>(dw[i]);
+        j.G[i] = d[0]; j.Cout[i] = d[1]; j.Cin[i] = d[2]; j.Cin_real[i] = d[3];
+        const int nn = d[1] * 9 * d[2];
+        j.tpo[i] = (nn >= 524288 || d[0] <= 4) ? 4 : ((nn >= 65536 || d[0] <= 16) ? 16 : 64);   // (as the single form)
+        const int opb = 256 / j.tpo[i] * 4, blocks = (nn + opb - 1) / opb;
+        if (blocks > gx) gx = blocks;
+    }
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_all, dim3(gx, n), dim3(256), 0, static_cast<hipStream_t>(stream), j);
     CHECK_LAUNCH();
     return VQA_OK;
 }

@@ -92,11 +92,20 @@ __device__ __forceinline__ float act_grad(float y, int act) {
 
 // i / d for 0 <= i < 2^22 and a runtime d, with inv = 1.0f / d from the host: a float multiply and two
 // corrections instead of the ~40-instruction integer division sequence.
-__device__ __forceinline__ int fastdiv(int i, int d, float inv) {
+// (0 <= i < 2^24, 0 < d < 2^24: the products are 24-bit multiplies - v_mul_lo_u32 is a quarter-rate instruction and
+// the index arithmetic of the conv prologues and tile loops was full of it)
+__device__ __forceinline__ int fastdivmod(int i, int d, float inv, int& rem) {
     int q = (int)((float)i * inv);
-    q -= (q * d > i);
-    q += ((q + 1) * d <= i);
+    int r = i - __mul24(q, d);
+    const int up = r >= d, dn = r < 0;
+    q += up - dn;
+    r += (dn ? d : 0) - (up ? d : 0);
+    rem = r;
     return q;
+}
+__device__ __forceinline__ int fastdiv(int i, int d, float inv) {
+    int rem;
+    return fastdivmod(i, d, inv, rem);
 }
 
 // Sum over the 16 lanes that share lane>>4 (the lanes holding different D columns of the same rows).

@@ -61,6 +61,9 @@ template <typename T, int CK> struct ConvCfg {
     static constexpr int VPP = CK * (int)sizeof(T) / 16;     // 16-byte vectors per patch pixel
 };
 
+#ifndef VQA_MFMA_STATS
+#define VQA_MFMA_STATS 1
+#endif
 #ifdef VQA_STAMPS
 __device__ unsigned long long g_stamps[16384][12];
 #define STAMP(i) do { if (threadIdx.x == 0) { const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
@@ -72,7 +75,7 @@ __device__ unsigned long long g_stamps[16384][12];
 // One workgroup per (tile, image, channel block): the multi-chunk (Cin > CK) layers, which are MFMA-bound and
 // want their registers for the accumulators and the chunk prefetch rather than for persistent-loop state.
 template <typename T, int CK, int NBF, int VAR>   // VAR: 0 plain, 1 XF (input BatchNorm + ReLU), 2 BST (see ConvArgs)
-__global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv3x3_igemm_tile(ConvArgs a) {   // (two waves per SIMD)
     constexpr bool XF = VAR == 1, BST = VAR == 2;
     using Cfg = ConvCfg<T, CK>;
     constexpr int VEC = Cfg::VEC, KC = Cfg::KC, KP = Cfg::KP, NS = Cfg::NS, PXB = Cfg::PXB, WROWB = Cfg::WROWB,
@@ -101,17 +104,21 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     } else if (unit >= nunits) return;
     const int ut = unit / zb;
     const int co0 = (unit - ut * zb) * NB;
-    const int b = fastdiv(ut, tiles_img, a.inv_tiles), tile = ut - b * tiles_img;
+    int tile, tx;
+    const int b = fastdivmod(ut, tiles_img, a.inv_tiles, tile);
+    // the coefficient rows go to LDS (one element per thread: Cin <= 256, 4 * NB <= 256, checked by the launcher): the
+    // loads leave here and are written behind the first chunk's loads, so that nothing waits for them alone
+    float cf0 = 0.f, cf1 = 0.f;
     if constexpr (XF) {                                         // (read by the first stash: barrier below)
-        for (int i = tid; i < a.Cin; i += 256) {
-            coefl[i] = a.in_scale[i];
-            coefl[a.Cin + i] = a.in_shift[i];
-        }
+        const int i = tid < a.Cin ? tid : 0;
+        cf0 = a.in_scale[i];
+        cf1 = a.in_shift[i];
     }
     if constexpr (BST) {                                        // [4][NB] of this channel block (read in the epilogue)
-        for (int i = tid; i < 4 * NB; i += 256) coefl[i] = a.bn_coef[(i / NB) * a.Cout + co0 + i % NB];
+        const int i = tid < 4 * NB ? tid : 0;
+        cf0 = a.bn_coef[(i / NB) * a.Cout + co0 + i % NB];
     }
-    const int ty = fastdiv(tile, a.tiles_x, a.inv_tx), tx = tile - ty * a.tiles_x;
+    const int ty = fastdivmod(tile, a.tiles_x, a.inv_tx, tx);
     const int oy0 = ty * a.R, ox0 = tx * a.CW;
     const int MT = a.R * a.CW;
     const T* w = static_cast<const T*>(a.w);
@@ -135,13 +142,19 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     for (int j = 0; j < NPV; ++j) {
         const int i = tid + j * 256;
         const int px = i / VPP, vv = i % VPP;
-        const int py = fastdiv(px, PW, a.inv_pw), pxx = px - py * PW;
+        int pxx;
+        const int py = fastdivmod(px, PW, a.inv_pw, pxx);
         const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
-        const bool ok = i < PPIX * VPP && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
-        psrc[j] = ok ? (unsigned)((iy * a.IW + ix) * a.Cin + vv * VEC) * (unsigned)sizeof(T) : 0x80000000u;
+        // (unsigned compares fold the two-sided range tests; everything is computed for every lane and selected -
+        // the compiler turned the conditional forms into a branch per vector; 24-bit multiplies: the launcher keeps
+        // IH * IW and Cin below 2^24)
+        const bool ok = i < PPIX * VPP && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+        const unsigned src = (unsigned)(__mul24(__mul24(iy, a.IW) + ix, a.Cin) + vv * VEC) * (unsigned)sizeof(T);
+        psrc[j] = ok ? src : 0x80000000u;
         // vectors beyond the patch go to a per-thread dump slot: the stash is straight-line code (a branch per vector
         // cut it into 15 basic blocks per chunk, each with its own wait)
-        pdst[j] = i < PPIX * VPP ? py * PROWB + pxx * PXB + vv * 16 : dump + tid * 16;
+        const int dst = __mul24(py, PROWB) + __mul24(pxx, PXB) + vv * 16;
+        pdst[j] = i < PPIX * VPP ? dst : dump + tid * 16;
     }
     uint4 pv[NPV], wv[NWV];
     auto fetch = [&](int ch) {
@@ -181,6 +194,12 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     // the first chunk's loads leave before anything else is computed: the fragment decode, the bias and the BST loads
     // below run under their latency (in-kernel stamps: the un-overlapped first fetch was 9-16 % of a workgroup's life)
     fetch(0);
+    if constexpr (XF) {
+        if (tid < a.Cin) { coefl[tid] = cf0; coefl[a.Cin + tid] = cf1; }
+    }
+    if constexpr (BST) {
+        if (tid < 4 * NB) coefl[tid] = cf0;
+    }
     // per-fragment pixel decode.  The tile's fragments of 16 consecutive pixels are dealt to the waves round-robin
     // (fragment f of wave w = fragment 4f + w of the tile) and a wave skips the MFMAs of fragments beyond the tile:
     // the small deep maps fill only part of the 16 slots (10x10: 7, 12x12: 9, 14x14: 13), and dealt in blocks of four
@@ -190,12 +209,12 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
         const int m = (f * 4 + wave) * 16 + r;
-        int pr = 0, pc = 0;
-        bool ok = m < MT;
-        if (ok) { pr = fastdiv(m, a.CW, a.inv_cw); pc = m - pr * a.CW; }
-        ok = ok && (oy0 + pr < a.OH) && (ox0 + pc < a.OW);
-        pbase[f] = pr * PROWB + pc * PXB;
-        opix[f] = ok ? ((b * a.OH + oy0 + pr) * a.OW + ox0 + pc) : -1;
+        int pc;
+        int pr = fastdivmod(m < MT ? m : 0, a.CW, a.inv_cw, pc);
+        const bool ok = m < MT && (oy0 + pr < a.OH) && (ox0 + pc < a.OW);
+        pbase[f] = __mul24(pr, PROWB) + __mul24(pc, PXB);
+        const int op = __mul24(b * a.OH + oy0 + pr, a.OW) + ox0 + pc;
+        opix[f] = ok ? op : -1;
     }
 
     f32x4 acc[4][NBF];
@@ -205,14 +224,22 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
         for (int n = 0; n < NBF; ++n) acc[f][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float bv[NBF][4];                                       // bias of this lane's channels, loaded up front
+    {
+        const bool hasb = !BST && a.bias;                   // (one 16-byte load per block from a valid address, selected)
+        const float* bsrc = hasb ? a.bias + co0 + q * 4 : reinterpret_cast<const float*>(a.w);
 #pragma unroll
-    for (int n = 0; n < NBF; ++n)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[n][e] = (!BST && a.bias) ? a.bias[co0 + n * 16 + q * 4 + e] : 0.f;
-    // BST: this lane's 4 channels of the lower layer's y at each of its output pixels, loaded up front (a whole
-    // chunk loop of lead time; out-of-tile pixels read zeros beyond the buffer)
+        for (int n = 0; n < NBF; ++n) {
+            const float4 t = *reinterpret_cast<const float4*>(bsrc + n * 16);
+            bv[n][0] = hasb ? t.x : 0.f; bv[n][1] = hasb ? t.y : 0.f;
+            bv[n][2] = hasb ? t.z : 0.f; bv[n][3] = hasb ? t.w : 0.f;
+        }
+    }
+    // BST: this lane's 4 channels of the lower layer's y at each of its output pixels, loaded during the LAST chunk's
+    // MFMA phase (out-of-tile pixels read zeros beyond the buffer): they take the registers the chunk prefetch no
+    // longer needs there - loaded up front they are live through the whole loop, and the 64-channel form then needs
+    // 264 registers: one wave per SIMD instead of two
     Raw4<T> yv[BST ? 4 : 1][BST ? NBF : 1];
-    if constexpr (BST) {
+    auto load_y = [&]() {
         const unsigned ybytes = (unsigned)a.B * a.OH * a.OW * a.Cout * (unsigned)sizeof(T);
         const __amdgpu_buffer_rsrc_t bybuf = buffer_of(a.bn_y, ybytes);
 #pragma unroll
@@ -221,7 +248,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
             for (int n = 0; n < NBF; ++n)
                 yv[f][n] = buffer_load_raw4<T>(bybuf, opix[f] >= 0 ? (unsigned)(opix[f] * a.Cout + co0 + n * 16 + q * 4) *
                                                                        (unsigned)sizeof(T) : ybytes);
-    }
+    };
     if constexpr (XF) __syncthreads();                          // coefl is read by the first stash
 
     const int nchunks = a.Cin / CK;
@@ -230,12 +257,15 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     auto chunks = [&](auto nf_tag) {
         constexpr int NF = decltype(nf_tag)::value;
         STAMP(1);
-        for (int ch = 0; ch < nchunks; ++ch) {
+        auto chunk = [&](int ch, auto last_tag) {
             stash(ch);
             if (ch == 0) STAMP(2);
             __syncthreads();
             if (ch == 0) STAMP(3);
-            if (ch + 1 < nchunks) fetch(ch + 1);
+            constexpr int LAST = decltype(last_tag)::value;     // 0 no, 1 yes, 2 run-time test
+            if constexpr (LAST == 0) fetch(ch + 1);
+            else if constexpr (LAST == 2) { if (ch + 1 < nchunks) fetch(ch + 1); }
+            else if constexpr (BST) load_y();
             // ---- MFMA over 9 taps x CK channels
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -260,6 +290,12 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
             if (ch == 0) STAMP(4);
             __syncthreads();
             if (ch == 0) STAMP(5);
+        };
+        if constexpr (BST) {                                    // (peeled only where the last chunk differs: the plain
+            for (int ch = 0; ch + 1 < nchunks; ++ch) chunk(ch, std::integral_constant<int, 0>{});   // forms need more
+            chunk(nchunks - 1, std::integral_constant<int, 1>{});                                    // registers peeled)
+        } else {
+            for (int ch = 0; ch < nchunks; ++ch) chunk(ch, std::integral_constant<int, 2>{});
         }
         STAMP(6);
     };
@@ -283,6 +319,9 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
     for (int n = 0; n < NBF; ++n)
 #pragma unroll
         for (int h = 0; h < 2; ++h) s1[n][h] = s2[n][h] = f32x2{0.f, 0.f};
+    // bf16: the BatchNorm statistics are taken by MFMA from the transposed tile (below), not per element here - the
+    // rows of pixels outside the image are then written as zeros
+    constexpr bool MS = VQA_MFMA_STATS && sizeof(T) == 2 && !BST;
     auto finish = [&](auto mode_tag) {
         constexpr bool RELU = (decltype(mode_tag)::value & 1) != 0, STATS = (decltype(mode_tag)::value & 2) != 0;
 #pragma unroll
@@ -292,7 +331,10 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
 #pragma unroll
             for (int n = 0; n < NBF; ++n) {
                 const f32x4 bias4 = {bv[n][0], bv[n][1], bv[n][2], bv[n][3]};
-                const Packed4<T> o = epilogue4<T, RELU, STATS>(acc[f][n], bias4, okf, s1[n], s2[n]);
+                Packed4<T> o = epilogue4<T, RELU, STATS && !MS>(acc[f][n], bias4, okf, s1[n], s2[n]);
+                if constexpr (MS && STATS) {
+                    if (opix[f] < 0) o = Packed4<T>{};
+                }
                 store_packed4<T>(reinterpret_cast<T*>(ew + (f * 16 + r) * EROW) + n * 16 + q * 4, o);
             }
         }
@@ -329,6 +371,37 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
         // [4 waves][NB][2] behind the transpose regions: the sums are ready before any global store is issued, so the
         // barrier below does not wait for stores
         float* red = reinterpret_cast<float*>(smem + 4 * 64 * EROW + 4 * 64 * 4);
+        if constexpr (MS) {
+            // Sum y and sum y^2 over this wave's 64 pixels per channel as two MFMAs per (16-channel block, 32 pixels):
+            // the fragment F (k = pixel, 16 channels; transposing LDS reads of the tile just written) is BOTH operands
+            // of the Gram product F^T F, whose diagonal is sum y^2, and the B operand under an all-ones A for sum y.
+            // ~3.5 VALU per accumulator element (unpack, mask, add, fma: ~900 instructions per wave) become ~60.
+            if constexpr (sizeof(T) == 2) {
+                const int rq = r >> 2, p4 = r & 3;
+                const bf16 one = (bf16)1.0f;
+                const bf16x8 ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+                for (int n = 0; n < NBF; ++n) {
+                    f32x4 gram = {0.f, 0.f, 0.f, 0.f}, ssum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 64; ks += 32) {
+                        const unsigned char* ad = ew + (n * 16 + 4 * p4) * 2 + (ks + q * 4 + rq) * EROW;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ad));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(ad + 16 * EROW));
+                        const bf16x8 fr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        gram = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr, fr, gram, 0, 0, 0);
+                        ssum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fr, ssum, 0, 0, 0);
+                    }
+                    // D[row 4q + e][col r]: the diagonal entry of channel r sits in lane group q = r >> 2, register r & 3
+                    const float d01 = (r & 1) ? gram[1] : gram[0], d23 = (r & 1) ? gram[3] : gram[2];
+                    const float dg = (r & 2) ? d23 : d01;
+                    float* dst = red + (wave * NB + n * 16 + r) * 2;
+                    if (q == 0) dst[0] = ssum[0];
+                    if (q == rq) dst[1] = dg;
+                }
+            }
+        } else {
 #pragma unroll
         for (int n = 0; n < NBF; ++n) {
             float t1[4] = {s1[n][0].x, s1[n][0].y, s1[n][1].x, s1[n][1].y};
@@ -340,6 +413,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_tile(ConvArgs a) {
                 *reinterpret_cast<float4*>(dst) = make_float4(t1[0], t2[0], t1[1], t2[1]);
                 *reinterpret_cast<float4*>(dst + 4) = make_float4(t1[2], t2[2], t1[3], t2[3]);
             }
+        }
         }
         __syncthreads();
         if (tid < NB * 2) {
@@ -637,6 +711,10 @@ int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
     } else {
         if (G != total) return VQA_ERR_ARG;
         if ((double)a.B * a.IH * a.IW * a.Cin * sizeof(T) >= 2147483648.0) return VQA_ERR_ARG;   // (offset sentinel 2^31)
+        // the kernel's 24-bit index products, its one-coefficient-per-thread rows and its 16-byte bias loads
+        if ((long)a.IH * a.IW >= (1 << 24) || (long)a.B * a.OH >= (1 << 24) || a.OW >= (1 << 24) || a.Cin > 256 ||
+            (reinterpret_cast<uintptr_t>(a.bias) & 15) != 0)
+            return VQA_ERR_ARG;
         hipLaunchKernelGGL(kt, dim3(8 * ((total * zb + 7) / 8)), dim3(256), lds, s, a);
     }
     CHECK_LAUNCH();

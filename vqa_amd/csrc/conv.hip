@@ -108,16 +108,15 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv3x3_igemm_til
     const int b = fastdivmod(ut, tiles_img, a.inv_tiles, tile);
     // the coefficient rows go to LDS (one element per thread: Cin <= 256, 4 * NB <= 256, checked by the launcher): the
     // loads leave here and are written behind the first chunk's loads, so that nothing waits for them alone
+    // (threads beyond the row re-write element 0 with the same value: a conditional write lets the compiler sink the
+    // loads into its block, behind the chunk's loads, and the write then waits for all of them)
     float cf0 = 0.f, cf1 = 0.f;
+    const int cfi = XF ? (tid < a.Cin ? tid : 0) : (tid < 4 * NB ? tid : 0);
     if constexpr (XF) {                                         // (read by the first stash: barrier below)
-        const int i = tid < a.Cin ? tid : 0;
-        cf0 = a.in_scale[i];
-        cf1 = a.in_shift[i];
+        cf0 = a.in_scale[cfi];
+        cf1 = a.in_shift[cfi];
     }
-    if constexpr (BST) {                                        // [4][NB] of this channel block (read in the epilogue)
-        const int i = tid < 4 * NB ? tid : 0;
-        cf0 = a.bn_coef[(i / NB) * a.Cout + co0 + i % NB];
-    }
+    if constexpr (BST) cf0 = a.bn_coef[(cfi / NB) * a.Cout + co0 + cfi % NB];   // [4][NB] of this block (epilogue)
     const int ty = fastdivmod(tile, a.tiles_x, a.inv_tx, tx);
     const int oy0 = ty * a.R, ox0 = tx * a.CW;
     const int MT = a.R * a.CW;
@@ -133,6 +132,20 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv3x3_igemm_til
     constexpr int NWV = (NB * WV + 255) / 256;
     // Out-of-image vectors get a byte offset >= 2^31, beyond the buffer (the launcher keeps x below 2 GiB): the
     // hardware answers such a buffer load with zeros - the zero padding needs no mask at the LDS write.
+    uint4 pv[NPV], wv[NWV];
+    auto fetch_w = [&](int ch) {
+        const T* wsrc = w + ((long)ch * a.Cout + co0) * KP;     // the chunk's NB rows are contiguous
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
+            const int i = tid + j * 256;
+            wv[j] = *reinterpret_cast<const uint4*>(wsrc + (i < NB * WV ? i : 0) * VEC);
+        }
+    };
+    // the first chunk's loads leave before anything else is computed - the weights, which need no plan, first: the
+    // staging plan, the fragment decode and the bias loads below run under their latency (in-kernel stamps: the
+    // un-overlapped first fetch was 9-16 % of a workgroup's life)
+    fetch_w(0);
+    __builtin_amdgcn_sched_barrier(0);
     const unsigned xbytes = (unsigned)a.B * a.IH * a.IW * a.Cin * (unsigned)sizeof(T);
     const __amdgpu_buffer_rsrc_t xbuf = buffer_of(a.x, xbytes);
     const unsigned img0 = (unsigned)b * a.IH * a.IW * a.Cin * (unsigned)sizeof(T);
@@ -156,18 +169,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv3x3_igemm_til
         const int dst = __mul24(py, PROWB) + __mul24(pxx, PXB) + vv * 16;
         pdst[j] = i < PPIX * VPP ? dst : dump + tid * 16;
     }
-    uint4 pv[NPV], wv[NWV];
-    auto fetch = [&](int ch) {
+    auto fetch_p = [&](int ch) {
         const unsigned base = img0 + (unsigned)(ch * CK) * (unsigned)sizeof(T);
 #pragma unroll
         for (int j = 0; j < NPV; ++j) pv[j] = buffer_load16(xbuf, psrc[j] + base);
-        const T* wsrc = w + ((long)ch * a.Cout + co0) * KP;     // the chunk's NB rows are contiguous
-#pragma unroll
-        for (int j = 0; j < NWV; ++j) {
-            const int i = tid + j * 256;
-            wv[j] = *reinterpret_cast<const uint4*>(wsrc + (i < NB * WV ? i : 0) * VEC);
-        }
     };
+    auto fetch = [&](int ch) { fetch_p(ch); fetch_w(ch); };
     auto stash = [&](int ch) {
         float isc[VEC], ish[VEC];                               // XF: this thread's channel vector (256 % VPP == 0)
         if constexpr (XF) {
@@ -191,15 +198,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv3x3_igemm_til
             if (NB * WV % 256 == 0 || i < NB * WV) *reinterpret_cast<uint4*>(wl + (i / WV) * WROWB + (i % WV) * 16) = t;
         }
     };
-    // the first chunk's loads leave before anything else is computed: the fragment decode, the bias and the BST loads
-    // below run under their latency (in-kernel stamps: the un-overlapped first fetch was 9-16 % of a workgroup's life)
-    fetch(0);
-    if constexpr (XF) {
-        if (tid < a.Cin) { coefl[tid] = cf0; coefl[a.Cin + tid] = cf1; }
-    }
-    if constexpr (BST) {
-        if (tid < 4 * NB) coefl[tid] = cf0;
-    }
+    fetch_p(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (XF) { coefl[cfi] = cf0; coefl[a.Cin + cfi] = cf1; }
+    if constexpr (BST) coefl[cfi] = cf0;
     // per-fragment pixel decode.  The tile's fragments of 16 consecutive pixels are dealt to the waves round-robin
     // (fragment f of wave w = fragment 4f + w of the tile) and a wave skips the MFMAs of fragments beyond the tile:
     // the small deep maps fill only part of the 16 slots (10x10: 7, 12x12: 9, 14x14: 13), and dealt in blocks of four

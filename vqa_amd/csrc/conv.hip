@@ -528,8 +528,9 @@ __global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) vo
     uint4 pv[NPV];
     int fb = 0, foy0 = 0, fox0 = 0;                             // image / output origin of the fetched tile
     auto fetch = [&](int t) {
-        const int b = fastdiv(t, tiles, a.inv_tiles), tl = t - b * tiles;
-        const int ty = fastdiv(tl, a.tiles_x, a.inv_tx), tx = tl - ty * a.tiles_x;
+        int tl, tx;
+        const int b = fastdivmod(t, tiles, a.inv_tiles, tl);
+        const int ty = fastdivmod(tl, a.tiles_x, a.inv_tx, tx);
         const int oy0 = ty * a.R, ox0 = tx * a.CW;
         fb = b; foy0 = oy0; fox0 = ox0;
         const unsigned org = (unsigned)((b * a.IH + oy0) * a.IW + ox0) * a.Cin * (unsigned)sizeof(T);
@@ -577,7 +578,8 @@ __global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) vo
                 const bool ok = coy0 + pr < a.OH && cox0 + pc < a.OW;
 #pragma unroll
                 for (int n = 0; n < NBF; ++n) {
-                    yoff[f][n] = ok ? yt0 + (unsigned)((pr * a.OW + pc) * a.Cout + n * 16) * (unsigned)sizeof(T) : ybytes;
+                    yoff[f][n] = ok ? yt0 + (unsigned)(__mul24(__mul24(pr, a.OW) + pc, a.Cout) + n * 16) * (unsigned)sizeof(T)
+                                    : ybytes;
                     yv[f][n] = buffer_load_raw4<T>(bybuf, yoff[f][n]);
                 }
             }
@@ -619,7 +621,8 @@ __global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) vo
                     const bool ok = coy0 + pr < a.OH && cox0 + pc < a.OW;
                     const Packed4<T> o = epilogue4<T, RELU, STATS>(acc[f][n], bv, ok ? 1.f : 0.f, s1[n], s2[n]);
                     buffer_store_packed4<T>(
-                        ybuf, ok ? yt + (unsigned)((pr * a.OW + pc) * a.Cout + n * 16) * (unsigned)sizeof(T) : ybytes, o);
+                        ybuf, ok ? yt + (unsigned)(__mul24(__mul24(pr, a.OW) + pc, a.Cout) + n * 16) * (unsigned)sizeof(T)
+                                 : ybytes, o);
                 }
             }
         };
@@ -709,6 +712,7 @@ int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
     }
     if (persistent) {
         if (G < 1 || G > total) return VQA_ERR_ARG;
+        if (a.OW >= (1 << 24) || a.Cout >= (1 << 24) || total >= (1 << 24)) return VQA_ERR_ARG;   // 24-bit index products
         hipLaunchKernelGGL(kp, dim3(G, zb), dim3(256), lds, s, a);
     } else {
         if (G != total) return VQA_ERR_ARG;

@@ -18,6 +18,8 @@ bias = torch.zeros(cout, device='cuda')
 wpk = M.pack_weights(w, cin, dt, False)
 wpk_d = M.pack_weights(w, cin, dt, True)
 img = (torch.randint(0, 256, (B, 3, 224, 224), device='cuda').float() / 255).half()
+isc = torch.rand(cin, device='cuda') + 0.5
+ish = torch.randn(cin, device='cuda') * 0.1
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for it in range(2):
@@ -27,6 +29,10 @@ for it in range(2):
             M.first_fwd(img, w, bias, pads[0], True)
         elif kind == 'first_wgrad':
             M.first_wgrad(img, dy, pads[0])
+        elif kind == 'fwdxf':
+            M.conv_fwd(x, wpk, bias, cout, pads[li], True, in_coeffs=(isc, ish))
+        elif kind == 'wgradxf':
+            M.conv_wgrad(x, dy, M.CHANNELS[li], pads[li], in_coeffs=(isc, ish))
         elif kind == 'fwd':
             M.conv_fwd(x, wpk, bias, cout, pads[li], True)
         elif kind == 'dgrad':

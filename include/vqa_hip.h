@@ -43,7 +43,10 @@ int vqa_conv_pack_all(void* stream, int dtype, int n, const void* const* w, void
  * tile; G persistent workgroups per output-channel block walk the (image, tile) pairs - take G from
  * vqa_conv3x3_plan() (resident workgroups of the instantiation x 256 CUs; -1 = unsupported shape).  `stats` (may be
  * NULL) receives G rows of per-channel (sum, sum of squares) of y, [G][Cout][2], for the BatchNorm that follows.
- * x and y are addressed through 32-bit byte offsets (buffer resources): each must be smaller than 4 GiB.
+ * x and y are addressed through 32-bit byte offsets (buffer resources): each must be smaller than 4 GiB.  The
+ * multi-chunk kernel (Cin larger than one channel chunk: 32 for bf16, 16 for f32) further needs x < 2 GiB, Cin <= 256,
+ * IH * IW and B * OH below 2^24 (24-bit index products) and `bias` 16-byte aligned; the BatchNorm statistics of a bf16
+ * call are the sums over the ROUNDED outputs as stored (formed by MFMA from the tile on its way out).  Status 1 otherwise.
  * in_scale / in_shift ([Cin] f32, both or neither; pad must be 0): x is the RAW output of the previous conv and the
  * input is relu(in_scale * x + in_shift) - that layer's nn.BatchNorm2d + nn.ReLU (cnn.py:23-24, ...), applied while
  * the input tile is staged, so the normalised activation is never written (bit-identical to vqa_bn_act_pool_fwd

@@ -53,6 +53,32 @@ def test_conv_fwd_dgrad_wgrad_exact(prec, B, cin, cout, H, W, pad):
     assert torch.equal(dw.cpu(), wr.grad)
 
 
+@pytest.mark.parametrize('B,cin,cout,H,W,pad', [(1, 64, 128, 19, 21, 0), (2, 128, 64, 33, 18, 2), (3, 256, 256, 12, 12, 0),
+                                                (2, 64, 32, 31, 17, 2), (1, 96, 64, 45, 45, 0)])
+def test_multi_chunk_statistics_are_the_sums_of_the_stored_outputs(B, cin, cout, H, W, pad):
+    """bf16 multi-chunk conv (Cin > 32): the BatchNorm statistics are formed by MFMA from the transposed bf16 tile on
+    its way out (conv.hip: F^T F and 1^T F over the tile's pixels).  Random data, tiles that hang over the image's
+    edges and partly filled fragment slots: the rows must sum to the sums over the STORED outputs (products of bf16
+    values are exact in f32; only the f32 summation order differs: rtol 2e-5), and the same call with relu = 1 and no
+    statistics must store the same values clamped at 0."""
+    from vqa_amd import cnn as C
+    torch.manual_seed(cin + cout + H + W)
+    dt = torch.bfloat16
+    x = torch.randn(B, H, W, cin, device='cuda').to(dt)
+    w = torch.randn(cout, cin, 3, 3, device='cuda') * 0.05
+    bias = torch.randn(cout, device='cuda')
+    wpk = C.pack_weights(w, cin, dt, dgrad=False)
+    y, stats = C.conv_fwd(x, wpk, bias, cout, pad, True)
+    y_ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(dt).float(), bias, padding=pad).permute(0, 2, 3, 1)
+    assert torch.allclose(y.float(), y_ref, rtol=2e-2, atol=2e-2)
+    s = stats.double().sum(0)
+    yd = y.double()
+    assert torch.allclose(s[:, 0], yd.sum((0, 1, 2)), rtol=2e-5, atol=1e-3)
+    assert torch.allclose(s[:, 1], (yd * yd).sum((0, 1, 2)), rtol=2e-5, atol=1e-3)
+    y2, none = C.conv_fwd(x, wpk, bias, cout, pad, False, relu=True)
+    assert none is None and torch.equal(y2, torch.clamp_min(y, 0))
+
+
 @pytest.mark.parametrize('img_dtype', [torch.float16, torch.float32])
 @pytest.mark.parametrize('B,H,W,pad', [(2, 20, 20, 2), (3, 13, 37, 0), (1, 70, 226, 2), (2, 33, 18, 5), (2, 9, 9, 1),
                                        (1, 5, 300, 0), (1, 300, 6, 1)])

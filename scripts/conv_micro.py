@@ -18,6 +18,8 @@ bias = torch.zeros(cout, device='cuda')
 wpk = M.pack_weights(w, cin, dt, False)
 wpk_d = M.pack_weights(w, cin, dt, True)
 img = (torch.randint(0, 256, (B, 3, 224, 224), device='cuda').float() / 255).half()
+by = torch.randn(B, IH, IH, cin, device='cuda').to(dt)
+bcoef = torch.rand(4, cin, device='cuda') + 0.5
 isc = torch.rand(cin, device='cuda') + 0.5
 ish = torch.randn(cin, device='cuda') * 0.1
 torch.cuda.synchronize()
@@ -35,6 +37,8 @@ for it in range(2):
             M.conv_wgrad(x, dy, M.CHANNELS[li], pads[li], in_coeffs=(isc, ish))
         elif kind == 'fwd':
             M.conv_fwd(x, wpk, bias, cout, pads[li], True)
+        elif kind == 'dgradbst':
+            M.conv_fwd(dy, wpk_d, None, cin, 2 - pads[li], False, kind='dgrad', bst=(by, bcoef))
         elif kind == 'dgrad':
             M.conv_fwd(dy, wpk_d, None, cin, 2 - pads[li], False, kind='dgrad')
         else:

@@ -148,7 +148,9 @@ __device__ __forceinline__ long window_base(unsigned px, int PH, int PW, int H, 
 template <typename T, int POOL, bool NT>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd(const T* __restrict__ y, T* __restrict__ a,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       int B, int H, int W, int C, int passes) {
+                                                       int B, int H, int W, int C, int passes, int rev) {
+    // (rev: the workgroups take their chunks from the tensor's end - see unit_walk, common.h)
+    const unsigned bx = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     using S = Stream<T, NT>;
     constexpr int N = S::N, U = POOL ? kFwdPoolU : kFwdU;
     const int CV = C / N;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd(const T* __restrict__ y, 
     float sc[N], sh[N];
     coeffs<N>(scale, cv, sc);
     coeffs<N>(shift, cv, sh);
-    long i = (long)blockIdx.x * (256 * U) * passes + threadIdx.x;
+    long i = (long)bx * (256 * U) * passes + threadIdx.x;
     for (int p = 0; p < passes; ++p, i += 256 * U) {
         if (i >= total) break;
         if (POOL == 0) {
@@ -217,12 +219,14 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd(const T* __restrict__ y, 
 template <typename T, int POOL, bool NT, bool YS = false>
 __global__ __launch_bounds__(256) void bn_pool_rows_fwd(const T* __restrict__ y, T* __restrict__ a,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                                        int PH, int H, int W, int C, T* __restrict__ ysel = nullptr) {
+                                                        int PH, int H, int W, int C, int rev,
+                                                        T* __restrict__ ysel = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using S = Stream<T, NT>;
     constexpr int N = S::N;
     const int CV = C / N, PW = W / 2;
-    const int b = blockIdx.x / PH, ph = blockIdx.x - b * PH;
+    const int bx = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int b = bx / PH, ph = bx - b * PH;
     const int nv = 2 * W * CV;                                  // 16-byte vectors of the row pair
     const v4u* src = reinterpret_cast<const v4u*>(y + ((long)(b * H + 2 * ph) * W) * C);
     v4u* lds = reinterpret_cast<v4u*>(smem);
@@ -292,7 +296,8 @@ __global__ __launch_bounds__(256) void bn_pool_rows_fwd(const T* __restrict__ y,
 
 // per-thread partial sums (a1, a2 for the thread's channel vector cv = tid % CV) -> one row of `part` per workgroup
 template <int N>
-__device__ __forceinline__ void reduce_rows(float (&a1)[N], float (&a2)[N], int CV, int C, float* __restrict__ part) {
+__device__ __forceinline__ void reduce_rows(float (&a1)[N], float (&a2)[N], int CV, int C, float* __restrict__ part,
+                                            unsigned bx /* the workgroup's row: its chunk number */) {
     __shared__ float red[4][512];   // [wave][channel][2], C <= 256
     // lanes with equal cv inside a wave: offsets CV, 2CV, ... (CV <= 64, power of two)
 #pragma unroll
@@ -316,7 +321,7 @@ __device__ __forceinline__ void reduce_rows(float (&a1)[N], float (&a2)[N], int 
     // waves hold the same channels when CV <= 64 (CV divides 64): sum the 4 waves in fixed order
     for (int t = threadIdx.x; t < C * 2; t += blockDim.x) {
         const float s4 = rw[t] + rw[per_wave + t] + rw[2 * per_wave + t] + rw[3 * per_wave + t];
-        part[(long)blockIdx.x * C * 2 + t] = s4;
+        part[(long)bx * C * 2 + t] = s4;
     }
 }
 
@@ -328,7 +333,10 @@ template <typename T, bool APPLY, int pool, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd(const T* __restrict__ y, const T* __restrict__ dout, T* __restrict__ dy,
                                               const float* scale, const float* shift, const float* mean,
                                               const float* invstd, const float* c1, const float* c2,
-                                              float* __restrict__ part, int B, int H, int W, int C, int passes) {
+                                              float* __restrict__ part, int B, int H, int W, int C, int passes,
+                                              int rev) {
+    // (rev: chunks from the tensor's end; the partial rows keep their chunk's number, so the sums are the same bits)
+    const unsigned bx = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     using S = Stream<T, NT>;
     constexpr int N = S::N, U = pool ? kBwdPoolU : kBwdU;
     const int CV = C / N;                       // channel vectors; power of two <= 64
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(256) void bn_bwd(const T* __restrict__ y, const T* 
 #pragma unroll
     for (int e = 0; e < N; ++e) a1[e] = a2[e] = 0.f;
     constexpr int np = pool ? 4 : 1;
-    long i = (long)blockIdx.x * (256 * U) * passes + threadIdx.x;
+    long i = (long)bx * (256 * U) * passes + threadIdx.x;
     for (int p = 0; p < passes; ++p, i += 256 * U) {
         if (i >= total) break;
         float g[U][N], v[U][np][N];
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(256) void bn_bwd(const T* __restrict__ y, const T* 
         }
     }
     if (!APPLY) {
-        reduce_rows<N>(a1, a2, CV, C, part);
+        reduce_rows<N>(a1, a2, CV, C, part, bx);
     }
 }
 
@@ -514,7 +522,7 @@ extern "C" int vqa_bn_act_pool_fwd(void* stream, int dtype, const void* y, void*
         const dim3 rgrid((unsigned)(B * (H / 2)));
 #define GY(T, NT) hipLaunchKernelGGL((bn_pool_rows_fwd<T, 1, NT, true>), rgrid, dim3(256), row_pair, s,          \
                                      static_cast<const T*>(y), static_cast<T*>(a), scale, shift, H / 2, H, W, C, \
-                                     static_cast<T*>(ysel))
+                                     vqa_walk_rev(64), static_cast<T*>(ysel))
         if (dtype == VQA_BF16) { if (nt) GY(bf16, true); else GY(bf16, false); }
         else { if (nt) GY(float, true); else GY(float, false); }
 #undef GY
@@ -524,7 +532,8 @@ extern "C" int vqa_bn_act_pool_fwd(void* stream, int dtype, const void* y, void*
     if (pool && row_pair <= 64 * 1024 && H >= 2 && W >= 2) {
         const dim3 rgrid((unsigned)(B * (H / 2)));
 #define GR(T, P, NT) hipLaunchKernelGGL((bn_pool_rows_fwd<T, P, NT>), rgrid, dim3(256), row_pair, s, \
-                                        static_cast<const T*>(y), static_cast<T*>(a), scale, shift, H / 2, H, W, C)
+                                        static_cast<const T*>(y), static_cast<T*>(a), scale, shift, H / 2, H, W, C, \
+                                        vqa_walk_rev(64))
 #define GRN(T, P) do { if (nt) GR(T, P, true); else GR(T, P, false); } while (0)
 #define GRP(T) do { if (pool == 1) GRN(T, 1); else GRN(T, 2); } while (0)
         if (dtype == VQA_BF16) GRP(bf16); else GRP(float);
@@ -536,7 +545,7 @@ extern "C" int vqa_bn_act_pool_fwd(void* stream, int dtype, const void* y, void*
     }
     const dim3 grid(grid_of(total, U, passes));
 #define GO(T, P, NT) hipLaunchKernelGGL((bn_act_pool_fwd<T, P, NT>), grid, dim3(256), 0, s, static_cast<const T*>(y), \
-                                        static_cast<T*>(a), scale, shift, B, H, W, C, passes)
+                                        static_cast<T*>(a), scale, shift, B, H, W, C, passes, vqa_walk_rev(64))
 #define GN(T, P) do { if (nt) GO(T, P, true); else GO(T, P, false); } while (0)
 #define GP(T) do { if (pool == 0) GN(T, 0); else if (pool == 1) GN(T, 1); else GN(T, 2); } while (0)
     if (dtype == VQA_BF16) GP(bf16); else GP(float);
@@ -576,7 +585,7 @@ extern "C" int vqa_bn_bwd(void* stream, int dtype, int apply, const void* y, con
     const bool nt = use_nt((ny + nd + (apply ? ny : 0.0)) * esz) && !(apply && pool);
 #define GO(T, AP, P, NT) hipLaunchKernelGGL((bn_bwd<T, AP, P, NT>), grid, dim3(256), 0, s, static_cast<const T*>(y), \
                                             static_cast<const T*>(dout), static_cast<T*>(dy), scale, shift, mean, \
-                                            invstd, c1, c2, part, B, H, W, C, passes)
+                                            invstd, c1, c2, part, B, H, W, C, passes, vqa_walk_rev(apply ? 128 : 256))
 #define GN(T, AP, P) do { if (nt) GO(T, AP, P, true); else GO(T, AP, P, false); } while (0)
 #define GP(T, AP) do { if (pool == 0) GN(T, AP, 0); else if (pool == 1) GN(T, AP, 1); else GN(T, AP, 2); } while (0)
     if (dtype == VQA_BF16) { if (apply) GP(bf16, true); else GP(bf16, false); }

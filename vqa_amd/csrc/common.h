@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -65,13 +66,37 @@ template <> struct Mma<bf16> {
 #ifndef VQA_XCD_WALK
 #define VQA_XCD_WALK 1
 #endif
-struct UnitWalk { int first, step, end; };
-__device__ __forceinline__ UnitWalk unit_walk(int x, int G, int total) {
+// rev != 0: every workgroup takes ITS units in descending order (unit(t) = lo + hi - 1 - t over its range [lo, hi)):
+// a consumer that walks a tensor larger than the 256 MB Infinity Cache in the producer's order finds the head evicted
+// and evicts the tail before it gets there; walking it back to front it starts with what the producer wrote last
+// (scripts/src/mall_micro.hip: 411 MB re-read at 3.7 TB/s front to back, 4.5 TB/s back to front).
+// VQA_WALK_REV (bit mask in the environment, read once per process): which streaming kernels walk back to front -
+// 1 plain single-chunk conv, 2 conv with the fused input BatchNorm, 4 data gradient with the BatchNorm-backward sums,
+// 8 weight gradient, 16 first-layer forward, 32 first-layer weight gradient, 64 BatchNorm / pool forward,
+// 128 BatchNorm backward apply pass, 256 BatchNorm backward reduce pass.
+// Default 4, measured in the step (same box, 3 alternations of 60 steps each): the data gradient of a layer and its
+// weight gradient are enqueued on two streams but each is a persistent grid that fills the chip, so they run one after
+// the other over the same two tensors (dy and the lower layer's y, 411-418 MB each in block 1): walking them from
+// opposite ends, the second starts with what the first read last.  4.240 -> 4.202 and 4.298 -> 4.265 ms/step; every
+// other bit alone or with it is within noise (8 alone gains the same, 4 + 8 together nothing: same direction again).
+#ifndef VQA_WALK_REV_DEFAULT
+#define VQA_WALK_REV_DEFAULT 4
+#endif
+static inline int vqa_walk_rev(int bit) {
+    static const int mask = [] { const char* e = getenv("VQA_WALK_REV"); return e ? atoi(e) : VQA_WALK_REV_DEFAULT; }();
+    return (mask & bit) != 0;
+}
+struct UnitWalk {
+    int first, step, end, flip;
+    __device__ __forceinline__ int unit(int t) const { return flip < 0 ? t : flip - t; }
+};
+__device__ __forceinline__ UnitWalk unit_walk(int x, int G, int total, int rev = 0) {
     if (VQA_XCD_WALK && (G & 7) == 0 && total >= G) {
         const int k = x & 7;
-        return {(int)(((long)total * k) >> 3) + (x >> 3), G >> 3, (int)(((long)total * (k + 1)) >> 3)};
+        const int lo = (int)(((long)total * k) >> 3), hi = (int)(((long)total * (k + 1)) >> 3);
+        return {lo + (x >> 3), G >> 3, hi, rev ? lo + hi - 1 : -1};
     }
-    return {x, G, total};
+    return {x, G, total, rev ? total - 1 : -1};
 }
 
 // Head activations (reference vqa_model.py:54: nn.ReLU() if activation == 'relu' else nn.SELU()).  act codes of the

@@ -44,6 +44,7 @@ struct ConvArgs {
     // forward statistics - its reduce pass (bn.hip) never runs, d is not re-read.
     const void* bn_y;
     const float* bn_coef;
+    int rev;            // persistent kernels: walk the units back to front (unit_walk, common.h)
 };
 
 template <typename T, int CK> struct ConvCfg {
@@ -560,8 +561,8 @@ __global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) vo
         }
     };
 
-    const UnitWalk uw = unit_walk(blockIdx.x, gridDim.x, total);
-    fetch(uw.first);
+    const UnitWalk uw = unit_walk(blockIdx.x, gridDim.x, total, a.rev);
+    fetch(uw.unit(uw.first));
     for (int t = uw.first; t < uw.end; t += uw.step) {
         stash();
         __syncthreads();
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) vo
                 }
             }
         }
-        if (t + uw.step < uw.end) fetch(t + uw.step);
+        if (t + uw.step < uw.end) fetch(uw.unit(t + uw.step));
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -748,6 +749,7 @@ struct WgradArgs {
     float inv_cw, inv_pw, inv_tx, inv_tiles;
     const float* in_scale;   // XF kernels: x is the previous conv's raw output, the input is relu(in_scale*x + in_shift)
     const float* in_shift;   // (see ConvArgs; pad == 0 only)
+    int rev;                 // walk the pixel tiles back to front (unit_walk, common.h)
 };
 
 // One workgroup: NB = 64 output channels x CK input channels x 9 taps, looping over pixel tiles
@@ -880,12 +882,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
             if (i < (MTP << dsh)) *reinterpret_cast<uint4*>(dyl + (i >> dsh) * DYB + (i & (dvp - 1)) * 16) = t;
         }
     };
-    const UnitWalk uw = unit_walk(blockIdx.x, gridDim.x, total);
-    fetch(uw.first);
+    const UnitWalk uw = unit_walk(blockIdx.x, gridDim.x, total, a.rev);
+    fetch(uw.unit(uw.first));
     for (int t = uw.first; t < uw.end; t += uw.step) {
         stash();
         __syncthreads();
-        if (t + uw.step < uw.end) fetch(t + uw.step);
+        if (t + uw.step < uw.end) fetch(uw.unit(t + uw.step));
         for (int ks = wk * KC; ks < MTP; ks += nwk * KC) {
             if constexpr (sizeof(T) == 2) {
                 // bf16: lane i = 4*rq + p of a 16-lane group supplies the address of k-row rq, channels 4p..4p+3;
@@ -1182,7 +1184,8 @@ static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* w
     if ((double)B * IH * IW * Cin * esz_ >= 4294967040.0 || (double)B * OH * OW * Cout * esz_ >= 4294967040.0) return bad;
     const int tx_ = (OW + CW - 1) / CW, ty_ = (OH + R - 1) / R;
     ConvArgs a{x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
-               1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), relu, in_scale, in_shift, bn_y, bn_coef};
+               1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), relu, in_scale, in_shift, bn_y, bn_coef,
+               vqa_walk_rev(in_scale ? 2 : (bn_y ? 4 : 1))};
     if (dtype == VQA_BF16) {
         if (Cin % 32 == 0) return dispatch_nb<bf16, 32>(s, a, G, plan_only);
         if (Cin == 16) return dispatch_nb<bf16, 16>(s, a, G, plan_only);
@@ -1232,7 +1235,7 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     const int COW = Cout >= 64 ? 64 : Cout;      // output channels per workgroup
     if ((COW != 16 && COW != 32 && COW != 64) || Cout % COW) return VQA_ERR_ARG;
     WgradArgs a{x, dy, part, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
-                1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), in_scale, in_shift};
+                1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), in_scale, in_shift, vqa_walk_rev(8)};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int MT = R * CW, PPIX = (R + 2) * (CW + 2);
     int status = VQA_ERR_ARG;

@@ -31,6 +31,7 @@ struct FirstArgs {
     // backward coefficients [16] each (bn.hip: dy = scale * (dz - c1 - xhat * c2), dz = z > 0 ? g : 0)
     const bf16* g;
     const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd, *bn_c1, *bn_c2;
+    int rev;             // walk the tiles back to front (unit_walk, common.h)
 };
 
 constexpr int PMAX = 384;                       // host bound on (R+2)*(CW+2)
@@ -215,8 +216,8 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
         ox0 = (tl - ty * a.tiles_x) * a.CW;
     };
     int fb, foy0, fox0;
-    const UnitWalk uw = unit_walk(blockIdx.x, gridDim.x, total);
-    tile_org(uw.first, fb, foy0, fox0);
+    const UnitWalk uw = unit_walk(blockIdx.x, gridDim.x, total, a.rev);
+    tile_org(uw.unit(uw.first), fb, foy0, fox0);
     fetch_pixels<TI>(a, ibuf, ibytes, plane, pl, fb, foy0, fox0, pv);
     // Loads and stores share one counter per wave (s_waitcnt vmcnt) and complete out of order with respect to each
     // other, so the wait for a tile's pixels is also a wait for every store issued before it.  The stores of tile t
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
         __syncthreads();
         const int b = fb, oy0 = foy0, ox0 = fox0;
         if (t + uw.step < uw.end) {
-            tile_org(t + uw.step, fb, foy0, fox0);
+            tile_org(uw.unit(t + uw.step), fb, foy0, fox0);
             fetch_pixels<TI>(a, ibuf, ibytes, plane, pl, fb, foy0, fox0, pv);
         }
 #pragma unroll
@@ -384,8 +385,8 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
         }
         return make_uint4(ow[0], ow[1], ow[2], ow[3]);
     };
-    const UnitWalk uw = unit_walk(blockIdx.x, gridDim.x, total);
-    fetch(uw.first);
+    const UnitWalk uw = unit_walk(blockIdx.x, gridDim.x, total, a.rev);
+    fetch(uw.unit(uw.first));
     __syncthreads();                                              // (coef)
     for (int t = uw.first; t < uw.end; t += uw.step) {
         stash_patch(patch, 3 * PP, pv);
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
             if (i < MTP * 2) *reinterpret_cast<uint4*>(dyl + i * 16) = tv;
         }
         __syncthreads();
-        if (t + uw.step < uw.end) fetch(t + uw.step);
+        if (t + uw.step < uw.end) fetch(uw.unit(t + uw.step));
         for (int ks = wave * 32; ks < MTP; ks += 128) {
             bf16x8 fa, fb0, fb1;
 #pragma unroll
@@ -469,6 +470,7 @@ extern "C" int vqa_conv3x3_first_fwd(void* stream, int in_dtype, const void* ima
     a.wscale = wscale;
     a.relu = relu;
     a.flip = flip;
+    a.rev = vqa_walk_rev(16);
     if (!images || !w || !y || !first_args(a, B, IH, IW, OH, OW, pad, R, CW, PMAX_F)) return VQA_ERR_ARG;
     if (G < 1 || G > a.tiles_x * a.tiles_y * B) return VQA_ERR_ARG;
     size_t lds = (size_t)((R + 2) * (CW + 2) + 1) * 8;       // the patch pixels and the spare one, 8 bytes each
@@ -520,6 +522,7 @@ extern "C" int vqa_conv3x3_first_wgrad(void* stream, int in_dtype, const void* i
     a.wscale = nullptr;
     a.relu = 0;
     a.flip = flip;
+    a.rev = vqa_walk_rev(32);
     a.g = nullptr;
     return first_wgrad_launch(stream, in_dtype, a, part, dw, G, B, IH, IW, OH, OW, pad, R, CW, false);
 }
@@ -534,6 +537,7 @@ extern "C" int vqa_conv3x3_first_wgrad_bn(void* stream, int in_dtype, const void
     a.wscale = nullptr;
     a.relu = 0;
     a.flip = flip;
+    a.rev = vqa_walk_rev(32);
     a.g = static_cast<const bf16*>(g);
     a.bn_scale = scale; a.bn_shift = shift; a.bn_mean = mean; a.bn_invstd = invstd; a.bn_c1 = c1; a.bn_c2 = c2;
     return first_wgrad_launch(stream, in_dtype, a, part, dw, G, B, IH, IW, OH, OW, pad, R, CW, true);

@@ -493,6 +493,40 @@ def test_encoder_with_pooled_bn_backward_matches_separate_pass(prec, monkeypatch
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 @pytest.mark.parametrize('streams', [True, False])
+def test_batch_sliced_backward_matches_whole_batch(prec, streams, monkeypatch):
+    """cnn.BWD_SLICES: the backward of a block in batch slices (apply pass -> weight gradient -> data gradient per
+    slice; by default only where a tensor exceeds the Infinity Cache) against the whole-batch form, forced here for
+    EVERY block (2 and 4 slices of a batch of 8): data gradients and BatchNorm gradients are the same arithmetic per
+    image, weight gradients and BatchNorm-backward sums differ in fp32 summation order only."""
+    from vqa_amd import cnn as M, synth
+    sd = {k[4:]: v for k, v in synth.state_dict(42, 64, 50, 30).items() if k.startswith('cnn.')}
+    img = synth.images(8, 3, 224).cuda()
+    monkeypatch.setattr(M, 'WGRAD_STREAM', streams)
+    monkeypatch.setattr(M, 'BWD_SLICE_MIN_MB', 0.0)
+    outs = []
+    for slices in (1, 2, 4):
+        monkeypatch.setattr(M, 'BWD_SLICES', slices)
+        m = M.CNN(2, 'max', precision=prec)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        out = m(img)
+        torch.manual_seed(1)
+        (out * torch.rand_like(out)).sum().backward()
+        torch.cuda.synchronize()
+        outs.append((out.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert M._bwd_slices(8, 1e9) == 4 and M._bwd_slices(6, 1e9) == 2
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0])
+        for k in o[1]:
+            a, b = o[1][k].double(), outs[0][1][k].double()
+            if float(b.norm()) == 0.0:
+                assert float(a.norm()) == 0.0
+            else:
+                assert float((a - b).norm() / b.norm()) < (1e-5 if prec == 'fp32' else 1e-2), k
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('streams', [True, False])
 def test_deferred_weight_gradient_reduction_is_bit_identical(prec, streams, monkeypatch):
     """cnn.DEFER_WGRAD_REDUCE (opt-in): the nine weight gradients leave their partial slabs and ONE launch
     (vqa_conv3x3_wgrad_reduce_all) sums them at the end of the backward - the same sums in the same order as a reduce

@@ -104,7 +104,8 @@ def _conv_tag(kind, B, OH, OW, cin_real, cout_real, x, y_elems_bytes, w_bytes, k
     return tag
 
 
-def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', relu=False, in_coeffs=None, bst=None):
+def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', relu=False, in_coeffs=None, bst=None,
+             out=None, stats_out=None):
     """x NHWC [B,IH,IW,Cin] -> y [B,OH,OW,Cout] (+ partial BN statistics rows).
     in_coeffs = (scale, shift): x is the previous conv's RAW output and the kernel applies that layer's BatchNorm +
     ReLU while it stages its input tile (pad must be 0).
@@ -113,9 +114,13 @@ def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', rel
     B, IH, IW, cin = x.shape
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
     R, CW = pick_tile(OH, OW)
-    y = torch.empty(B, OH, OW, cout, device=x.device, dtype=x.dtype)
+    y = torch.empty(B, OH, OW, cout, device=x.device, dtype=x.dtype) if out is None else out
     G = _plan(L.dt(x), B, IH, IW, cin, OH, OW, cout, pad, R, CW, 1 if in_coeffs is not None else (2 if bst else 0))
-    stats = torch.empty(G, cout, 2, device=x.device, dtype=torch.float32) if (want_stats or bst) else None
+    stats = None
+    if want_stats or bst:       # (out / stats_out: a batch slice of a larger call writes its part of the whole)
+        stats = torch.empty(G, cout, 2, device=x.device, dtype=torch.float32) if stats_out is None else stats_out
+        assert stats.shape[0] == G and stats.is_contiguous()
+    assert y.is_contiguous() and tuple(y.shape) == (B, OH, OW, cout)
     cr = cin if cin_real is None else cin_real
     # (algorithmic bytes of the launch: + the lower layer's y when its BatchNorm-backward sums are formed here)
     tag = lambda: _conv_tag(kind, B, OH, OW, cr, cout, x, y.numel() * y.element_size() * (2 if bst else 1),
@@ -143,9 +148,12 @@ def _plan(*key):
     return _plans[key]
 
 
-def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None, defer=None):
-    """defer (a list): the partial slabs are left unreduced and (part, dw, G, cout, cin, cin_real) is appended to it
-    for wgrad_reduce_all - one launch for all layers at the end of the backward."""
+def wgrad_rows(x, dy):
+    """G of conv_wgrad for these shapes (rows of its partial-slab workspace)."""
+    return _wgrad_geom(x, dy)[2]
+
+
+def _wgrad_geom(x, dy):
     B, IH, IW, cin = x.shape
     _, OH, OW, cout = dy.shape
     mt = 256 if x.dtype == torch.bfloat16 else 128
@@ -163,10 +171,27 @@ def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None, defer=None):
     waves = 4 if cow == 16 else 2
     per_cu = max(1, min(waves, (160 * 1024) // lds))
     G = max(1, min(tiles, (256 * per_cu) // pairs if pairs <= 256 * per_cu else 1))
+    return R, CW, G
+
+
+def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None, defer=None, part_out=None):
+    """defer (a list): the partial slabs are left unreduced and (part, dw, G, cout, cin, cin_real) is appended to it
+    for wgrad_reduce_all - one launch for all layers at the end of the backward.
+    part_out ([G, cout, 9, cin] f32): the slabs are written there and NOT reduced (a batch slice of a larger call: the
+    caller reduces the slabs of all slices at once, wgrad_reduce_all); returns None."""
+    B, IH, IW, cin = x.shape
+    _, OH, OW, cout = dy.shape
+    R, CW, G = _wgrad_geom(x, dy)
+    isc, ish = in_coeffs if in_coeffs is not None else (None, None)
+    if part_out is not None:
+        assert tuple(part_out.shape) == (G, cout, 9, cin) and part_out.is_contiguous()
+        tag = lambda: _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), cout * cin_real * 36)
+        L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part_out, None, G, B, IH, IW, cin, cin_real,
+               OH, OW, cout, pad, R, CW, isc, ish, tag=tag)
+        return None
     part = torch.empty(G, cout, 9, cin, device=x.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)
     tag = lambda: _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4)
-    isc, ish = in_coeffs if in_coeffs is not None else (None, None)
     L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw if defer is None else None, G, B, IH, IW, cin, cin_real,
            OH, OW, cout, pad, R, CW, isc, ish, tag=tag)
     if defer is not None:
@@ -355,6 +380,45 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
         if dbias is None:
             dbias = torch.zeros(C, device=dev, dtype=torch.float32)
         return None, dw, dbias, dgamma, dbeta, None
+    S = _bwd_slices(B, y.numel() * es)
+    if S > 1 and not first and need_dx and defer is None:
+        # Batch slices: apply pass -> weight gradient -> data gradient per B / S images, so that the slice's dy (and
+        # the lower layer's y, read by both gradients) is still in the 256 MB Infinity Cache when it is read again.
+        # Same-box A/B, 6 alternations of 60 steps: 4.231 -> 4.209 ms/step with 4 slices of block 1's second conv
+        # (411 MB per tensor); 2 slices the same, 8 slices (32 images per launch) +2.5 %, and slicing block 2 as well
+        # (205 MB tensors, which fit the cache whole) +0.4 %.
+        Bs = B // S
+        wd = wpk_d if wpk_d is not None else pack_weights(w, x.shape[3], x.dtype, dgrad=True)
+        dx = torch.empty_like(x)
+        dys = torch.empty_like(y)
+        IH, IW, cin = x.shape[1], x.shape[2], x.shape[3]
+        gd = _plan(L.dt(y), Bs, H, W, C, IH, IW, cin, 2 - pad, *pick_tile(IH, IW), 2 if bst else 0)
+        below = torch.empty(S * gd, cin, 2, device=dev, dtype=torch.float32) if bst else None
+        gw = wgrad_rows(x[:Bs], dys[:Bs])
+        part_w = torch.empty(S * gw, C, 9, cin, device=dev, dtype=torch.float32)
+        dw = dw_out if dw_out is not None else torch.empty(C, cin_real, 3, 3, device=dev, dtype=torch.float32)
+        cur = torch.cuda.current_stream()
+        for si in range(S):
+            sl = slice(si * Bs, (si + 1) * Bs)
+            tag = lambda: dict(kind='apply', shape=f'{H}x{W}x{C}', flops=0.0,
+                               bytes=float((2 * y[sl].numel() + d[sl].numel()) * es))
+            L.call('vqa_bn_bwd', L.dt(y), 1, y[sl], d[sl], dys[sl], scale, shift, mean, invstd, c1, c2, None, Bs, H, W,
+                   C, pool, tag=tag)
+            if side is not None:
+                side.wait_event(cur.record_event())
+            with torch.cuda.stream(side if side is not None else cur):
+                conv_wgrad(x[sl], dys[sl], cin_real, pad, in_coeffs=in_coeffs, part_out=part_w[si * gw:(si + 1) * gw])
+            conv_fwd(dys[sl], wd, None, cin, 2 - pad, False, kind='dgrad',
+                     bst=(bst[0][sl], bst[1]) if bst else None, out=dx[sl],
+                     stats_out=below[si * gd:(si + 1) * gd] if bst else None)
+        with torch.cuda.stream(side if side is not None else cur):
+            wgrad_reduce_all([(part_w, dw, S * gw, C, cin, cin_real)])
+        if side is not None:
+            for t in (dys, x, part_w):
+                t.record_stream(side)
+        if dbias is None:
+            dbias = torch.zeros(C, device=dev, dtype=torch.float32)
+        return dx, dw, dbias, dgamma, dbeta, below
     dy = torch.empty_like(y)
     tag = lambda: dict(kind='apply', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((2 * y.numel() + d.numel()) * es))
     L.call('vqa_bn_bwd', L.dt(y), 1, y, d, dy, scale, shift, mean, invstd, c1, c2, None, B, H, W, C, pool, tag=tag)
@@ -453,6 +517,26 @@ FUSE_POOL_BWD = int(os.environ.get('VQA_FUSE_POOL_BWD', '128'))
 # kernel time per step, but the one launch sits in the step's tail where nothing overlaps it, while the nine run under
 # the data-gradient chain (same-box A/B: 4.402 vs 4.378 ms/step).  Bit-identical either way.
 DEFER_WGRAD_REDUCE = os.environ.get('VQA_DEFER_WGRAD_REDUCE', '0') != '0'
+# backward of the blocks whose conv output is at least VQA_BWD_SLICE_MIN_MB in batch slices (block_bwd):
+# VQA_BWD_SLICES = 0 (default) picks the number of slices, 1 turns slicing off, N forces N slices
+BWD_SLICES = int(os.environ.get('VQA_BWD_SLICES', '0'))
+BWD_SLICE_MIN_MB = float(os.environ.get('VQA_BWD_SLICE_MIN_MB', '300'))
+
+
+def _bwd_slices(B, nbytes):
+    """Batch slices of a block's backward: tensors larger than the Infinity Cache are cut to ~100 MB per slice, but
+    never below 64 images' worth of the 224x224 first block per launch (more, smaller launches cost more than they
+    gain), and only into equal slices."""
+    if BWD_SLICES == 1 or nbytes < BWD_SLICE_MIN_MB * 1e6:
+        return 1
+    S = BWD_SLICES
+    if S == 0:
+        S = 2
+        while S < 8 and nbytes / S > 110e6:
+            S *= 2
+    while S > 1 and B % S:
+        S //= 2
+    return S
 _WGRAD_STREAMS = {}
 
 

@@ -502,7 +502,15 @@ static int passes_for(long total, int U, int max_grid) {
 // forward 226x226x16 0.155 -> 0.138 ms (6.1 TB/s), reduce 114x114x32 0.103 -> 0.077 ms; the POOLED apply pass is the
 // exception (224x224x16: 0.160 plain, 0.205 non-temporal): each of its store instructions fills half of every 64-byte
 // line (the even or the odd pixels of a row), which a write-back L2 merges and a streaming store cannot.
-static bool use_nt(double bytes) { return bytes > 256e6; }
+// (VQA_NT_MIN_MB in the environment, read once.  Same-box A/B of the step, 6 alternations of 60 steps: never
+// non-temporal 4.37 ms against 4.33 at 256 MB; 256 / 100 / 0 MB: 4.214 / 4.201 / 4.203.)
+#ifndef VQA_NT_MIN_MB_DEFAULT
+#define VQA_NT_MIN_MB_DEFAULT 100.0
+#endif
+static bool use_nt(double bytes) {
+    static const double min_mb = [] { const char* e = getenv("VQA_NT_MIN_MB"); return e ? atof(e) : VQA_NT_MIN_MB_DEFAULT; }();
+    return bytes > min_mb * 1e6;
+}
 constexpr int kReduceRows = 4096;   // 2048: reduce pass 3 % slower, 16384: 8 % slower (more partial rows to finalize)
 
 extern "C" int vqa_bn_act_pool_fwd(void* stream, int dtype, const void* y, void* a, const float* scale,

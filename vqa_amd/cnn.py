@@ -170,6 +170,8 @@ def _wgrad_geom(x, dy):
     # resident workgroups per CU: register-limited waves/SIMD of the instantiation, then LDS
     waves = 4 if cow == 16 else 2
     per_cu = max(1, min(waves, (160 * 1024) // lds))
+    if per_cu - WGRAD_RESERVE >= 2:
+        per_cu -= WGRAD_RESERVE
     G = max(1, min(tiles, (256 * per_cu) // pairs if pairs <= 256 * per_cu else 1))
     return R, CW, G
 
@@ -265,7 +267,7 @@ def first_fwd(images, w, bias, pad, want_stats, wscale=None, relu=False, mirror=
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
     R, CW = pick_first_tile(OH, OW)
     y = torch.empty(B, OH, OW, 16, device=images.device, dtype=torch.bfloat16)
-    G = min(B * (-(-OH // R)) * (-(-OW // CW)), 256 * 5)      # persistent workgroups: 5 resident per CU (92 VGPRs)
+    G = min(B * (-(-OH // R)) * (-(-OW // CW)), 256 * (5 - FIRST_RESERVE))   # persistent workgroups: 5 resident per CU (92 VGPRs)
     stats = torch.empty(G, 16, 2, device=images.device, dtype=torch.float32) if want_stats else None
     tag = lambda: dict(kind='first', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
                bytes=float(images.numel() * images.element_size() + y.numel() * 2 + w.numel() * 4))
@@ -282,7 +284,7 @@ def first_wgrad(images, dy, pad, out=None, mirror=False, bn=None):
     R, CW = pick_first_tile(OH, OW, 384)                      # (wide tiles: long runs of dy; 0.155 -> 0.139 ms)
     tiles = B * (-(-OH // R)) * (-(-OW // CW))
     # persistent workgroups: what is resident per CU (84 VGPRs -> 5 waves per SIMD; the fused kernel has 112 -> 4)
-    G = min(tiles, 256 * (4 if bn is not None else 5))
+    G = min(tiles, 256 * ((4 if bn is not None else 5) - FIRST_RESERVE))
     part = torch.empty(G, 16, 32, device=dy.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty(16, 3, 3, 3, device=dy.device, dtype=torch.float32)
     tag = lambda: dict(kind='first_wgrad', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
@@ -521,6 +523,8 @@ DEFER_WGRAD_REDUCE = os.environ.get('VQA_DEFER_WGRAD_REDUCE', '0') != '0'
 # VQA_BWD_SLICES = 0 (default) picks the number of slices, 1 turns slicing off, N forces N slices
 BWD_SLICES = int(os.environ.get('VQA_BWD_SLICES', '0'))
 BWD_SLICE_MIN_MB = float(os.environ.get('VQA_BWD_SLICE_MIN_MB', '300'))
+WGRAD_RESERVE = int(os.environ.get('VQA_WGRAD_RESERVE', '0'))
+FIRST_RESERVE = int(os.environ.get('VQA_FIRST_RESERVE', '0'))
 
 
 def _bwd_slices(B, nbytes):

@@ -62,6 +62,9 @@ template <typename T, int CK> struct ConvCfg {
     static constexpr int VPP = CK * (int)sizeof(T) / 16;     // 16-byte vectors per patch pixel
 };
 
+#ifndef VQA_PLAN_RESERVE_DEFAULT
+#define VQA_PLAN_RESERVE_DEFAULT 1
+#endif
 #ifndef VQA_MFMA_STATS
 #define VQA_MFMA_STATS 1
 #endif
@@ -707,6 +710,10 @@ int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
         if (!persistent) return total;
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kp, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        // VQA_PLAN_RESERVE (read once): workgroup slots per CU left free for the kernels of the other streams, as long
+        // as two remain
+        static const int reserve = [] { const char* e = getenv("VQA_PLAN_RESERVE"); return e ? atoi(e) : VQA_PLAN_RESERVE_DEFAULT; }();
+        if (per_cu - reserve >= 2) per_cu -= reserve;
         int g = (256 * per_cu) / zb;
         if (g < 1) g = 1;
         return g < total ? g : total;

@@ -711,9 +711,11 @@ int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kp, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         // VQA_PLAN_RESERVE (read once): workgroup slots per CU left free for the kernels of the other streams, as long
-        // as two remain
+        // as VQA_PLAN_RESERVE_KEEP (3) remain: 4 -> 3 costs the kernel nothing alone, 3 -> 2 costs it 4 % and gains the
+        // step nothing more
         static const int reserve = [] { const char* e = getenv("VQA_PLAN_RESERVE"); return e ? atoi(e) : VQA_PLAN_RESERVE_DEFAULT; }();
-        if (per_cu - reserve >= 2) per_cu -= reserve;
+        static const int keep = [] { const char* e = getenv("VQA_PLAN_RESERVE_KEEP"); return e ? atoi(e) : 3; }();
+        if (per_cu - reserve >= keep) per_cu -= reserve;
         int g = (256 * per_cu) / zb;
         if (g < 1) g = 1;
         return g < total ? g : total;

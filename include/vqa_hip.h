@@ -11,6 +11,9 @@
  *     state, caches no stream or device, allocates nothing, and is re-entrant (autograd worker threads call it) - the
  *     one exception is vqa_soft_accuracy_sum_noalloc, which owns a static per-GPU scratch array (see there);
  *   - the caller owns every buffer (inputs, outputs, workspaces, saved-for-backward tensors), all device memory;
+ *   - three speed-only switches are read from the environment once per process: VQA_PLAN_RESERVE,
+ *     VQA_WALK_REV, VQA_NT_MIN_MB - they change the order in which a kernel walks its tiles, the size of a persistent
+ *     grid or the cache policy of its accesses, never what is computed;
  *   - dtype codes: 0 = f32, 1 = bf16, 2 = f16 (image input only).  "T" below = the activation / MFMA dtype;
  *   - activations are NHWC; matrices are row-major with an explicit leading dimension in elements.
  */

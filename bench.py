@@ -237,6 +237,9 @@ def main():
                     help='NOT the headline: question encoder and weight gradients on the main stream for the whole run '
                          '(for rocprofv3 --kernel-trace: per-kernel durations without a concurrent kernel)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-buckets', action='store_true',
+                    help='NOT the headline: with one rank under torch.distributed.run, run the bucketed RCCL '
+                         'all-reduces anyway (the N > 1 step on one GPU: hooks, the collective stream, the joins)')
     ap.add_argument('--breakdown', action='store_true', help='also print the per-kernel time table to stderr')
     args = ap.parse_args()
 
@@ -269,7 +272,7 @@ def main():
                               precision=args.precision)
     assert len(model.gru.word_idx_mappings) == vocab, len(model.gru.word_idx_mappings)
     model = model.to(dev).train()
-    trainer = Trainer(model, lr=2e-3, max_norm=0.25)
+    trainer = Trainer(model, lr=2e-3, max_norm=0.25, force_buckets=args.force_buckets)
     B = args.batch
     seed = 1234 + rank                                          # every rank its own shard of the global batch
     batch = (synth.images(seed, B, args.image).to(dev), synth.questions(seed, B, args.tokens, vocab).to(dev),

@@ -37,3 +37,18 @@ def test_bench_under_torchrun_one_rank():
               'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
         assert k in out, k
     assert out['n_gpus'] == 1 and out['value'] > 0 and out['roofline']['frac'] > 0
+
+
+@pytest.mark.parametrize('extra', [[], ['--image', '448', '--tokens', '30', '--hidden', '2048']])
+def test_full_size_step_with_forced_buckets_under_torchrun(extra):
+    """The N > 1 step at the bench's full sizes on one GPU (`bench.py --force-buckets`: hook-driven bucketed all-reduces
+    on RCCL's stream beside the trainer's, the weight-gradient and the question encoder's streams - five streams on four
+    hardware queues): it must neither hang (a timeout fails the test) nor change the contract's line.  224x224 / H = 1024
+    and the 448x448 / T = 30 / H = 2048 variant, whose step once hung when a fifth compute stream was added."""
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1',
+                        '--master-addr', '127.0.0.1', '--master-port', '29735', os.path.join(ROOT, 'bench.py'),
+                        '--gpus', '1', '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--force-buckets'] + extra,
+                       cwd=ROOT, capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['n_gpus'] == 1 and out['value'] > 0 and out['ms_per_step'] > 0

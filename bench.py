@@ -172,8 +172,11 @@ def price(r, peak_tflops):
     return out
 
 
+ROOFLINE_STEPS = 5
+
+
 def roofline_leg(trainer, batch, precision='bf16'):
-    """One extra, instrumented step: HIP events around every C-ABI call on the launching stream (question encoder
+    """ROOFLINE_STEPS extra, instrumented steps (averaged per launch): HIP events around every C-ABI call on the launching stream (question encoder
     and weight gradients kept on the main stream for this step, so no launch is timed under a concurrent kernel).
     `roofline` = the device kernel with the largest total time, priced against the roof that binds the sum of ITS
     launches; `roofline_by_kernel` = the same for every kernel family that carries algorithmic work."""
@@ -187,11 +190,20 @@ def roofline_leg(trainer, batch, precision='bf16'):
     try:
         trainer.step(*batch)
         L.profile_start()
-        trainer.step(*batch)
+        for _ in range(ROOFLINE_STEPS):
+            trainer.step(*batch)
         prof = L.profile_stop()
     finally:
         VM.SIDE_STREAM, VM.HEAD_WGRAD_STREAM = side, hside
         CN.WGRAD_STREAM = wside
+    # the same launches in the same order every step: launch i of an entry point = the mean of its ROOFLINE_STEPS
+    # records (a single step's figure moves by +-3 % from run to run)
+    avg = {}
+    for name, recs in prof.items():
+        assert len(recs) % ROOFLINE_STEPS == 0, (name, len(recs))
+        c = len(recs) // ROOFLINE_STEPS
+        avg[name] = [(sum(recs[i + j * c][0] for j in range(ROOFLINE_STEPS)) / ROOFLINE_STEPS, recs[i][1]) for i in range(c)]
+    prof = avg
     totals = {k: sum(ms for ms, _ in v) for k, v in prof.items()}
     rows, fam = {}, {}
     for name, recs in prof.items():

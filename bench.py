@@ -200,9 +200,12 @@ def roofline_leg(trainer, batch, precision='bf16'):
     # records (a single step's figure moves by +-3 % from run to run)
     avg = {}
     for name, recs in prof.items():
-        assert len(recs) % ROOFLINE_STEPS == 0, (name, len(recs))
         c = len(recs) // ROOFLINE_STEPS
-        avg[name] = [(sum(recs[i + j * c][0] for j in range(ROOFLINE_STEPS)) / ROOFLINE_STEPS, recs[i][1]) for i in range(c)]
+        if c * ROOFLINE_STEPS == len(recs):
+            avg[name] = [(sum(recs[i + j * c][0] for j in range(ROOFLINE_STEPS)) / ROOFLINE_STEPS, recs[i][1])
+                         for i in range(c)]
+        else:       # (an entry point not called the same number of times in every step: per-step totals stay right)
+            avg[name] = [(ms / ROOFLINE_STEPS, tag) for ms, tag in recs]
     prof = avg
     totals = {k: sum(ms for ms, _ in v) for k, v in prof.items()}
     rows, fam = {}, {}

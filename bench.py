@@ -205,7 +205,9 @@ def roofline_leg(trainer, batch, precision='bf16'):
             avg[name] = [(sum(recs[i + j * c][0] for j in range(ROOFLINE_STEPS)) / ROOFLINE_STEPS, recs[i][1])
                          for i in range(c)]
         else:       # (an entry point not called the same number of times in every step: per-step totals stay right)
-            avg[name] = [(ms / ROOFLINE_STEPS, tag) for ms, tag in recs]
+            w = 1.0 / ROOFLINE_STEPS
+            avg[name] = [(ms * w, None if tag is None else dict(tag, flops=tag['flops'] * w, bytes=tag['bytes'] * w, _w=w))
+                         for ms, tag in recs]
     prof = avg
     totals = {k: sum(ms for ms, _ in v) for k, v in prof.items()}
     rows, fam = {}, {}
@@ -215,7 +217,7 @@ def roofline_leg(trainer, batch, precision='bf16'):
             for table, key in ((rows, name if not tag else f"{name}[{tag['kind']}]"), (fam, family)):
                 r = table.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
                 r['ms'] += ms
-                r['n'] += 1
+                r['n'] += (tag or {}).get('_w', 1)
                 if tag:
                     r['flops'] += tag['flops']
                     r['bytes'] += tag['bytes']

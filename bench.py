@@ -272,7 +272,11 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    if world > 1 or args.force_buckets:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29741')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)     # RCCL over xGMI
 
     from vqa_amd import synth
@@ -368,10 +372,7 @@ def main():
     value = world * B * args.steps / elapsed
 
     if args.mode == 'eval':
-        if world > 1:
-            dist.destroy_process_group()
-        if rank == 0:
-            print(json.dumps({'metric': 'eval samples/sec (node)', 'value': round(value, 1), 'unit': 'samples/s',
+XX, 'value': round(value, 1), 'unit': 'samples/s',
                               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                               'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
                               'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
@@ -391,7 +392,8 @@ def main():
                                f'{classes} answers, H={args.hidden}, V={vocab}, padding 2, max-pool, dropout 0',
                    'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}',
                    'weights': 'module-default init, seed 42', 'final_loss': round(final_loss, 3),
-                   **({'host_inputs': args.host_inputs} if args.host_inputs != 'off' else {})},
+                   **({'host_inputs': args.host_inputs} if args.host_inputs != 'off' else {}),
+                   **({'force_buckets': True} if args.force_buckets else {})},
         'step_tflops_algorithmic': round(value * GFLOP_PER_SAMPLE_TRAIN / 1e3, 2),
     }
     # every rank runs the instrumented step (it all-reduces like any other); rank 0 reports its own timings
@@ -418,7 +420,7 @@ def main():
             result['cpu_baseline'] = cpu_baseline(args.hidden, classes, vocab)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -48,7 +48,7 @@ int vqa_conv_pack_all(void* stream, int dtype, int n, const void* const* w, void
  * NULL) receives G rows of per-channel (sum, sum of squares) of y, [G][Cout][2], for the BatchNorm that follows.
  * x and y are addressed through 32-bit byte offsets (buffer resources): each must be smaller than 4 GiB.  The
  * multi-chunk kernel (Cin larger than one channel chunk: 32 for bf16, 16 for f32) further needs x < 2 GiB, Cin <= 256,
- * IH * IW and B * OH below 2^24 (24-bit index products) and `bias` 16-byte aligned; the BatchNorm statistics of a bf16
+ * IH * IW and B * OH below 2^22 (signed 24-bit index products, float quotients) and `bias` 16-byte aligned; the BatchNorm statistics of a bf16
  * call are the sums over the ROUNDED outputs as stored (formed by MFMA from the tile on its way out).  Status 1 otherwise.
  * in_scale / in_shift ([Cin] f32, both or neither; pad must be 0): x is the RAW output of the previous conv and the
  * input is relu(in_scale * x + in_shift) - that layer's nn.BatchNorm2d + nn.ReLU (cnn.py:23-24, ...), applied while
@@ -273,8 +273,9 @@ int vqa_soft_accuracy_sum(void* stream, const float* logits, const float* target
 /* NO COUNTERPART IN THE REFERENCE.  vqa_soft_accuracy_sum for callers that cannot allocate or hand over scratch: code
  * under HIP graph capture, tight serving / evaluation loops, harnesses that forbid hipMalloc.  Same result bit for bit;
  * the B floats of scratch live in a file-scope device array of the library (256 KiB per GPU, held until the process
- * ends; its address is looked up once per device, on the first call there).  No hipMalloc / hipFree, no workspace
- * argument.  B <= 65536: a larger batch returns 3 (VQA_ERR_CAPACITY) and launches nothing.  All calls on one GPU share
+ * ends; its address is looked up once per device, on the first call there - hipGetSymbolAddress is not a stream
+ * operation, so make that first call OUTSIDE a graph capture; every later call is two kernel launches and nothing
+ * else).  No hipMalloc / hipFree, no workspace argument.  B <= 65536: a larger batch returns 3 (VQA_ERR_CAPACITY) and launches nothing.  All calls on one GPU share
  * that GPU's array: calls that overlap there (two streams, two threads) race; calls ordered on one stream do not. */
 int vqa_soft_accuracy_sum_noalloc(void* stream, const float* logits, const float* target, int B, int C, int ldx,
                                   float* acc);

@@ -72,7 +72,9 @@ def test_persistent_matches_per_step(tmp_path, monkeypatch):
 
 
 @pytest.mark.parametrize('B,T,E,V,hot', [(256, 14, 300, 10000, 0.4), (64, 30, 300, 82, 0.5), (700, 14, 300, 500, 0.3),
-                                         (5, 3, 6, 7, 0.0), (1, 1, 300, 82, 0.0), (33, 9, 10, 40, 0.9)])
+                                         (5, 3, 6, 7, 0.0), (1, 1, 300, 82, 0.0), (33, 9, 10, 40, 0.9),
+                                         # V >= 2^19 with more than 4096 tokens in a chunk: 64-bit sort keys, 64 KB of LDS keys
+                                         (400, 14, 10, 524293, 0.2)])
 def test_embedding_backward_is_exact_and_deterministic(B, T, E, V, hot):
     """vqa_embed_bwd (sorted, no atomics) against the scatter-add in fp64: hot rows (the <pad> row takes `hot` of the
     tokens), out-of-vocabulary ids (dropped), more tokens than one sort chunk (700 x 14 > 8192), widths that are not a

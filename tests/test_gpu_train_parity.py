@@ -222,8 +222,15 @@ def test_dropout_replayed_vs_golden(prec, tmp_path):
     assert m._dropout_mask(4, torch.device('cuda')) == (None, None)
 
 
-@pytest.mark.parametrize('prec,tol_scalar,tol_update', [('fp32', 5e-3, 1e-2)])
-def test_three_steps_vs_golden(prec, tol_scalar, tol_update, tmp_path):
+# bf16 row: what three steps of the bf16 path keep of the reference's fp32 trajectory on this synthetic-weight model (the
+# loss goes 12104 -> 852 -> 2641).  Scalars and the smooth parameters' updates hold to a few percent; the running
+# MEANS of the deep layers do not (measured 0.11 on cnn.convolutions.22): after step 1 every weight has moved by lr *
+# sign(g), the image encoder's step-2 / step-3 activations are those of a different network wherever a near-zero
+# step-1 gradient took the other sign, and a batch mean is a small difference of large numbers.  The bound on them is
+# therefore loose and says so; how the bf16 path TRAINS is pinned by test_bf16_trajectory_tracks_fp32 below.
+@pytest.mark.parametrize('prec,tol', [('fp32', dict(tol_scalar=5e-3, tol_update=1e-2)),
+                                      ('bf16', dict(tol_scalar=5e-2, tol_update=8e-2, tol_var=5e-2, tol_mean=3e-1))])
+def test_three_steps_vs_golden(prec, tol, tmp_path):
     """Three whole training steps (Trainer: zero_grad -> fwd -> loss -> bwd -> clip 0.25 -> Adamax) on the B=32 case
     against the reference's state after its third step: losses and clip norms of steps 2 and 3, running statistics,
     and the accumulated updates of the smoothly-behaving parameters (tests/test_oracle_golden.py::SMOOTH)."""
@@ -238,12 +245,109 @@ def test_three_steps_vs_golden(prec, tol_scalar, tol_update, tmp_path):
         losses.append(float(tr.step(img, q, t, flip=False)))
         norms.append(float(tr.opt.total_norm))
     sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
-    # (fp32 only: in bf16 the chaotic image-encoder gradients of steps 2 and 3 - see SMOOTH - move the running means by
-    # 10 % and the comparison says nothing about the optimizer; bf16 gradients are pinned per step above)
-    worst = check_three_steps(c, sd, losses, norms, tol_scalar=tol_scalar, tol_update=tol_update)
+    worst = check_three_steps(c, sd, losses, norms, **tol)
     for k in range(10):
         assert int(m.cnn.convolutions[[1, 4, 8, 11, 15, 18, 22, 25, 29, 32][k]].num_batches_tracked) == 3
-    print(f'\n[3 steps {prec}] losses {losses} norms {norms} worst mean |update diff| / lr {worst:.2e}')
+    g = c['golden']
+    stat = {kind: max(rel_err(sd[k], g[f'stat3/{k}']) for k in c['sd'] if k.endswith(kind))
+            for kind in ('running_mean', 'running_var')}
+    print(f'\n[3 steps {prec}] losses {losses} norms {norms} worst mean |update diff| / lr {worst:.2e} '
+          f'running stats {stat}')
+
+
+def test_reference_loop_as_written(tmp_path):
+    """The reference's training loop, line for line as vqa_model.py:246-266 writes it, on the HIP module - no Trainer, no
+    SoftScoreBCELoss: `model.flip(images)`, `nn.BCEWithLogitsLoss(reduction='sum')`, `loss.backward()`,
+    `nn.utils.clip_grad_norm_(model.parameters(), max_norm=0.25, norm_type=2)`, `float(loss)`, `optim.Adamax(...).step()`
+    - for three steps on the B=32 case (fp32), against the imported reference's state after ITS third step (losses /
+    clip norms of steps 2 and 3, running statistics, p3samp/*).  The flip's coin is pinned to "no flip" (p = 0), as the
+    golden was recorded; that model.flip flips when the coin says so is checked at the end."""
+    import torch.nn as nn
+    import torch.optim as optim
+    from tests.test_oracle_golden import check_three_steps
+    c = load_case('h1024_p2_max_b32')
+    model = build_model(c, tmp_path, 'fp32')
+    model = model.to(model.device)
+    batch = {'image': c['images'], 'question': c['questions'], 'answer': c['targets']}
+    criterion = nn.BCEWithLogitsLoss(reduction='sum')
+    optimizer = optim.Adamax(model.parameters(), lr=2e-3)
+    model.flip.p = 0.0
+    train_epoch_losses, norms = list(), list()
+    model.train()
+    for i_batch in range(3):
+        optimizer.zero_grad()
+
+        images_batch_ = model.flip(batch['image'].cuda())
+        questions_batch_ = batch['question'].cuda()
+        target = batch['answer'].cuda()
+
+        output = model(images_batch_, questions_batch_)
+        loss = criterion(output, target)
+        loss.backward()
+
+        norms.append(float(nn.utils.clip_grad_norm_(model.parameters(), max_norm=0.25, norm_type=2)))
+
+        train_epoch_losses.append(float(loss))
+        optimizer.step()
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    worst = check_three_steps(c, sd, train_epoch_losses, norms)
+    assert train_epoch_losses[0] == pytest.approx(float(c['golden']['loss']), rel=3e-4)
+    print(f'\n[reference loop] losses {train_epoch_losses} norms {norms} worst mean |update diff| / lr {worst:.2e}')
+    model.flip.p = 1.0
+    x = batch['image'][:2].cuda()
+    assert torch.equal(model.flip(x), x.flip(-1))
+
+
+def test_bf16_trajectory_tracks_fp32(tmp_path):
+    """How the bf16 path TRAINS, against the fp32 path of the same library (which the tests above pin to the reference):
+    same module-default initialisation (seed 42, as bench.py and vqa_model.py:334), H = 1024, 224x224, four fixed
+    batches of 128 samples visited in turn for 40 Trainer steps (clip 0.25 + Adamax lr 2e-3, flips on with the same
+    coin sequence).  Per-step gradients of this model are chaotic in bf16 (test_b32_train_step_vs_golden), so the
+    statement is about the trajectory: the bf16 loss stays within a band of the fp32 loss at EVERY step, the two end at
+    the same mean loss over the last visit of the four batches, and the eval-mode soft accuracy on a fixed 256-sample
+    set (BatchNorm running statistics and all) differs by at most a stated delta.  Measured values: DESIGN.md section 2."""
+    import copy
+    import bench
+    import vqa_model
+    from vqa_amd import ops, synth
+    from vqa_amd.optim import Trainer
+    H, C, V, B, NB, STEPS = 1024, 3129, 10000, 128, 4, 40
+    qpath, lpath = bench.make_fixture(str(tmp_path), V, C)
+    torch.manual_seed(42)
+    base = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': H, 'n_layers': 1, 'train_question_path': qpath},
+                         lpath, 256, 2, 0.0, 'max', 'relu', precision='fp32')
+    batches = [(synth.images(100 + i, B, 224).cuda(), synth.questions(100 + i, B, 14, V).cuda(),
+                synth.targets(100 + i, B, C).cuda()) for i in range(NB)]
+    ev = (torch.cat([b[0] for b in batches[:2]]), torch.cat([b[1] for b in batches[:2]]),
+          torch.cat([b[2] for b in batches[:2]]))
+    curves, accs, eval_loss = {}, {}, {}
+    for prec in ('fp32', 'bf16'):
+        m = copy.deepcopy(base).set_precision(prec).cuda().train()
+        tr = Trainer(m, lr=2e-3, max_norm=0.25)
+        torch.manual_seed(7)                                   # the flip's coin sequence
+        curves[prec] = [float(tr.step(*batches[s % NB])) for s in range(STEPS)]
+        m.eval()
+        with torch.no_grad():
+            lo = m(ev[0], ev[1])
+            accs[prec] = float(ops.soft_accuracy_sum(lo, ev[2])) / ev[0].shape[0]
+            eval_loss[prec] = float(vqa_model.SoftScoreBCELoss()(lo, ev[2])) / ev[0].shape[0]
+    f, b = curves['fp32'], curves['bf16']
+    rel = [abs(x - y) / x for x, y in zip(f, b)]
+    print(f'\n[trajectory] fp32 loss {[round(x, 1) for x in f]}\n[trajectory] bf16 loss {[round(x, 1) for x in b]}\n'
+          f'[trajectory] max rel diff {max(rel):.3e} (first 10 steps {max(rel[:10]):.3e}), soft accuracy fp32 '
+          f'{accs["fp32"]:.4f} bf16 {accs["bf16"]:.4f}, eval loss / sample fp32 {eval_loss["fp32"]:.3f} bf16 '
+          f'{eval_loss["bf16"]:.3f}')
+    assert all(x == x for x in f + b)
+    assert f[-1] < 0.25 * f[0] and b[-1] < 0.25 * b[0]                     # both train
+    assert max(rel) < TRAJ_BAND, rel
+    last_f, last_b = sum(f[-NB:]) / NB, sum(b[-NB:]) / NB
+    assert abs(last_f - last_b) < TRAJ_FINAL * last_f
+    assert abs(accs['fp32'] - accs['bf16']) <= TRAJ_ACC_DELTA
+    assert abs(eval_loss['fp32'] - eval_loss['bf16']) < TRAJ_EVAL_LOSS * eval_loss['fp32']
+
+
+# bands of test_bf16_trajectory_tracks_fp32 (measured values in DESIGN.md section 2)
+TRAJ_BAND, TRAJ_FINAL, TRAJ_ACC_DELTA, TRAJ_EVAL_LOSS = 0.25, 0.10, 0.05, 0.15
 
 
 def test_clip_adamax_vs_torch_optim():
@@ -301,11 +405,19 @@ def test_gradient_accumulation_with_side_streams(prec, tmp_path, monkeypatch):
         m.zero_grad(set_to_none=True)
         crit(m(img, q), t).backward()
         h.remove()
-        out.append((twice, {k: p.grad.detach().clone() for k, p in m.named_parameters()}, seen[0]))
+        # a post-accumulate-grad hook that is not GradBuckets' own (a user's, DDP's, a logger's) reads p.grad on
+        # the calling stream right after the adoption: the head must have waited for its side-stream gradients
+        post = []
+        h2 = m.linear_inside_relu_last.weight_v.register_post_accumulate_grad_hook(lambda p: post.append(p.grad.clone()))
+        m.zero_grad(set_to_none=True)
+        crit(m(img, q), t).backward()
+        h2.remove()
+        out.append((twice, {k: p.grad.detach().clone() for k, p in m.named_parameters()}, seen[0], post[0]))
     for a, b in zip(out[0][:2], out[1][:2]):
         for k in a:
             assert torch.equal(a[k], b[k]), k
     assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][2], out[0][1]['fc.weight_v'])
+    assert torch.equal(out[0][3], out[1][3]) and torch.equal(out[0][3], out[0][1]['linear_inside_relu_last.weight_v'])
 
 
 def test_soft_accuracy_on_nan_and_inf_rows():

@@ -107,7 +107,7 @@ def oracle_steps(c, n_steps):
 SMOOTH = ('gru.', 'linear_inside_relu_image', 'linear_inside_relu_question', 'linear_inside_relu_last', 'fc.')
 
 
-def check_three_steps(c, sd, losses, norms, lr=2e-3, tol_scalar=5e-3, tol_update=1e-2):
+def check_three_steps(c, sd, losses, norms, lr=2e-3, tol_scalar=5e-3, tol_update=1e-2, tol_var=2e-3, tol_mean=5e-2):
     """Shared with the GPU test: state after three steps against the reference's."""
     g = c['golden']
     for s in (2, 3):
@@ -116,9 +116,9 @@ def check_three_steps(c, sd, losses, norms, lr=2e-3, tol_scalar=5e-3, tol_update
     worst = 0.0
     for k in c['sd']:
         if k.endswith('running_var'):
-            assert rel_err(sd[k], g[f'stat3/{k}']) < 2e-3, k
+            assert rel_err(sd[k], g[f'stat3/{k}']) < tol_var, k
         elif k.endswith('running_mean'):
-            assert rel_err(sd[k], g[f'stat3/{k}']) < 5e-2, k
+            assert rel_err(sd[k], g[f'stat3/{k}']) < tol_mean, k
         elif O.is_param(k) and k.startswith(SMOOTH):
             # compare the accumulated UPDATE (three steps of at most lr each), not the parameter it is added to
             idx = sample_idx(c['sd'][k].numel())

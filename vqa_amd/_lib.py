@@ -4,6 +4,7 @@ The library is loaded lazily at module scope, never stored on an nn.Module (the 
 modules: vqa_model.py:296).  There is NO CPU fallback: if the library is missing, every op raises."""
 import ctypes
 import os
+import re
 
 import torch
 
@@ -26,6 +27,9 @@ def lib():
             raise VqaHipError(f'{_PATH} not found: build it with `make` (hipcc --offload-arch=gfx950). '
                               'The VQA hot path has no CPU fallback.')
         _LIB = ctypes.CDLL(_PATH)
+        for name, (restype, argtypes) in declared_prototypes().items():
+            fn = getattr(_LIB, name)
+            fn.restype, fn.argtypes = restype, argtypes
     return _LIB
 
 
@@ -57,15 +61,11 @@ _FN = {}
 
 def call(name, *args):
     """Call an exported function: tensors -> device pointers, ints/floats passed by value, stream prepended.
-    The ctypes prototype is built on the first call of each function (tensor / None -> void*, float -> float,
-    anything else -> long; x86-64: int and long parameters both read it correctly) and reused afterwards."""
+    The ctypes prototypes are the declarations of include/vqa_hip.h (declared_prototypes(), set when the library is
+    loaded), so every argument is converted to the declared C type whatever Python type a call site passes."""
     fn = _FN.get(name)
     if fn is None:
-        fn = getattr(lib(), name)
-        fn.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p if (a is None or isinstance(a, torch.Tensor)) else
-                                           (ctypes.c_float if isinstance(a, float) else ctypes.c_long) for a in args]
-        fn.restype = ctypes.c_int
-        _FN[name] = fn
+        fn = _FN[name] = getattr(lib(), name)
     status = fn(_raw_stream(), *[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args])
     if status != 0:
         raise VqaHipError(f'{name} failed with status {status}', status)
@@ -83,12 +83,39 @@ def fits(name, *args, **kw):
     return True
 
 
+_HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'vqa_hip.h')
+_PROTOS = None
+
+
+def _ctype_of(param):
+    """C parameter declaration -> ctypes type: any pointer is a void*, scalars by their declared type."""
+    if '*' in param:
+        return ctypes.c_void_p
+    words = set(re.findall(r'[A-Za-z_]+', param)[:-1])          # the last identifier is the parameter's name
+    for key, ct in (('double', ctypes.c_double), ('float', ctypes.c_float), ('long', ctypes.c_long),
+                    ('unsigned', ctypes.c_uint), ('int', ctypes.c_int)):
+        if key in words:
+            return ct
+    raise VqaHipError(f'include/vqa_hip.h: cannot map parameter {param!r} to a ctypes type')
+
+
+def declared_prototypes():
+    """{name: (restype, [argtypes])} of every function include/vqa_hip.h declares (comments stripped)."""
+    global _PROTOS
+    if _PROTOS is None:
+        with open(_HEADER) as f:
+            text = re.sub(r'/\*.*?\*/', ' ', f.read(), flags=re.S)
+        protos = {}
+        for name, params in re.findall(r'\bint\s+(vqa_\w+)\s*\(([^)]*)\)\s*;', text):
+            plist = [p.strip() for p in params.split(',') if p.strip() and p.strip() != 'void']
+            protos[name] = (ctypes.c_int, [_ctype_of(p) for p in plist])
+        _PROTOS = protos
+    return _PROTOS
+
+
 def declared_symbols():
     """Names of every function include/vqa_hip.h declares."""
-    import re
-    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'vqa_hip.h')
-    with open(hdr) as f:
-        return sorted(set(re.findall(r'^int (vqa_\w+)\(', f.read(), flags=re.M)))
+    return sorted(declared_prototypes())
 
 
 # --- optional per-call device timing (bench.py's roofline leg): events on the launching stream around each call

@@ -11,7 +11,6 @@ or 'fp32' (exact-f32 MFMA).  There is no CPU path: on a CPU tensor the module ra
 """
 import os
 import functools
-import platform
 
 import torch
 import torch.nn as nn
@@ -648,7 +647,6 @@ class CNN(nn.Module):
     def __init__(self, padding=0, pooling='max', precision='bf16'):
         super(CNN, self).__init__()
         self.device = 'cuda:0' if torch.cuda.is_available() else 'cpu'
-        running_on_linux = 'Linux' in platform.platform()  # noqa: F841  (attribute parity with the reference)
         self.padding, self.pooling, self.precision = padding, pooling, precision
 
         def pool():

@@ -117,7 +117,8 @@ __device__ __forceinline__ float act_grad(float y, int act) {
 
 // i / d for 0 <= i < 2^22 and a runtime d, with inv = 1.0f / d from the host: a float multiply and two
 // corrections instead of the ~40-instruction integer division sequence.
-// (0 <= i < 2^24, 0 < d < 2^24: the products are 24-bit multiplies - v_mul_lo_u32 is a quarter-rate instruction and
+// (0 <= i < 2^23, 0 < d < 2^23 - __mul24 is the SIGNED 24-bit multiply, an operand with bit 23 set turns negative; the
+// hosts' guards refuse larger shapes: the products are 24-bit multiplies - v_mul_lo_u32 is a quarter-rate instruction and
 // the index arithmetic of the conv prologues and tile loops was full of it)
 __device__ __forceinline__ int fastdivmod(int i, int d, float inv, int& rem) {
     int q = (int)((float)i * inv);

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv3x3_igemm_til
         const int iy = oy0 + py - a.pad, ix = ox0 + pxx - a.pad;
         // (unsigned compares fold the two-sided range tests; everything is computed for every lane and selected -
         // the compiler turned the conditional forms into a branch per vector; 24-bit multiplies: the launcher keeps
-        // IH * IW and Cin below 2^24)
+        // IH * IW and Cin below 2^23: __mul24 is signed)
         const bool ok = i < PPIX * VPP && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
         const unsigned src = (unsigned)(__mul24(__mul24(iy, a.IW) + ix, a.Cin) + vv * VEC) * (unsigned)sizeof(T);
         psrc[j] = ok ? src : 0x80000000u;
@@ -722,13 +722,15 @@ int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
     }
     if (persistent) {
         if (G < 1 || G > total) return VQA_ERR_ARG;
-        if (a.OW >= (1 << 24) || a.Cout >= (1 << 24) || total >= (1 << 24)) return VQA_ERR_ARG;   // 24-bit index products
+        if (a.OW >= (1 << 22) || a.Cout >= (1 << 22) || total >= (1 << 22)) return VQA_ERR_ARG;   // signed 24-bit index products
         hipLaunchKernelGGL(kp, dim3(G, zb), dim3(256), lds, s, a);
     } else {
         if (G != total) return VQA_ERR_ARG;
         if ((double)a.B * a.IH * a.IW * a.Cin * sizeof(T) >= 2147483648.0) return VQA_ERR_ARG;   // (offset sentinel 2^31)
-        // the kernel's 24-bit index products, its one-coefficient-per-thread rows and its 16-byte bias loads
-        if ((long)a.IH * a.IW >= (1 << 24) || (long)a.B * a.OH >= (1 << 24) || a.OW >= (1 << 24) || a.Cin > 256 ||
+        // the kernel's 24-bit index products (__mul24 is the SIGNED multiply: it sign-extends from bit 23, so every
+        // operand must stay below 2^23, and fastdivmod's float quotient wants i < 2^22), its one-coefficient-per-thread
+        // rows and its 16-byte bias loads
+        if ((long)a.IH * a.IW >= (1 << 22) || (long)a.B * a.OH >= (1 << 22) || a.OW >= (1 << 22) || a.Cin > 256 ||
             (reinterpret_cast<uintptr_t>(a.bias) & 15) != 0)
             return VQA_ERR_ARG;
         hipLaunchKernelGGL(kt, dim3(8 * ((total * zb + 7) / 8)), dim3(256), lds, s, a);
@@ -1243,6 +1245,8 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     const int tx_ = (OW + CW - 1) / CW, ty_ = (OH + R - 1) / R;
     const int COW = Cout >= 64 ? 64 : Cout;      // output channels per workgroup
     if ((COW != 16 && COW != 32 && COW != 64) || Cout % COW) return VQA_ERR_ARG;
+    // fastdiv (common.h): float quotient + signed 24-bit products - tile numbers below 2^22
+    if ((long)B * tx_ * ty_ >= (1 << 22)) return VQA_ERR_ARG;
     WgradArgs a{x, dy, part, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
                 1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), in_scale, in_shift, vqa_walk_rev(8)};
     hipStream_t s = static_cast<hipStream_t>(stream);

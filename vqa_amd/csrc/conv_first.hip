@@ -458,6 +458,8 @@ bool first_args(FirstArgs& a, int B, int IH, int IW, int OH, int OW, int pad, in
     a.tiles_x = (OW + CW - 1) / CW; a.tiles_y = (OH + R - 1) / R;
     a.inv_cw = 1.0f / CW; a.inv_pw = 1.0f / (CW + 2); a.inv_tx = 1.0f / a.tiles_x;
     a.inv_tiles = 1.0f / (a.tiles_x * a.tiles_y);
+    // fastdiv (common.h): float quotient + signed 24-bit products - tile numbers and image widths below 2^22 / 2^23
+    if ((long)B * a.tiles_x * a.tiles_y >= (1 << 22) || (long)IH * IW >= (1 << 22)) return false;
     return true;
 }
 

@@ -207,7 +207,14 @@ __global__ __launch_bounds__(256) void embed_combine(int E, int accumulate, Embe
     const int per = (m + 3) / 4, j0 = wave * per, j1 = min(j0 + per, m);
     constexpr int W = VEC ? 4 : 1, U = 8;
     float* dst = demb + (long)id * E;
-    for (int e0 = lane * W; e0 < E; e0 += 64 * W) {
+    // Block-uniform trip count: every lane runs ceil(E / (64 W)) rounds and lanes whose columns lie beyond E are
+    // predicated off (loads clamped to column 0, nothing stored) - the two barriers per round are then reached by all
+    // 256 threads in convergent control flow (E = 300, W = 4: lanes 11..63 are idle in the second round).
+    const int rounds = (E + 64 * W - 1) / (64 * W);
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int e0 = rd * 64 * W + lane * W;
+        const bool live = e0 < E;
+        const int el = live ? e0 : 0;
         float acc[W];
 #pragma unroll
         for (int i = 0; i < W; ++i) acc[i] = 0.f;
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(256) void embed_combine(int E, int accumulate, Embe
             float v[U][W];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float* src = w.part + (long)(k + (j + u < j1 ? j + u : j1 - 1)) * E + e0;
+                const float* src = w.part + (long)(k + (j + u < j1 ? j + u : j1 - 1)) * E + el;
                 if constexpr (VEC) load4(src, v[u]);
                 else v[u][0] = src[0];
             }
@@ -226,12 +233,12 @@ __global__ __launch_bounds__(256) void embed_combine(int E, int accumulate, Embe
                     for (int i = 0; i < W; ++i) acc[i] += v[u][i];
                 }
         }
-        if (wave > 0) {
+        if (wave > 0 && live) {
 #pragma unroll
             for (int i = 0; i < W; ++i) comb[(wave - 1) * E + e0 + i] = acc[i];
         }
-        __syncthreads();                                                   // (uniform: every lane of the block loops alike)
-        if (wave == 0) {
+        __syncthreads();
+        if (wave == 0 && live) {
 #pragma unroll
             for (int i = 0; i < W; ++i) {
                 float t = acc[i] + comb[e0 + i];
@@ -273,7 +280,12 @@ extern "C" int vqa_embed_bwd(void* stream, const long* q, const float* dx, int B
         int logP = 10;
         while ((1 << logP) < P) ++logP;
         const bool k32 = ((unsigned long long)V << logP) < 0xFFFFFFFFull;
-        const size_t lds = (size_t)P * (k32 ? 4 : 8);      // <= 64 KB
+        const size_t lds = (size_t)P * (k32 ? 4 : 8);      // <= 64 KB of keys, beside the kernel's static red[16]
+        if (lds + 64 > 64 * 1024) {                        // (64-bit keys at P = 8192: over the default 64 KB limit)
+            if (hipFuncSetAttribute(k32 ? (const void*)embed_sort<unsigned> : (const void*)embed_sort<unsigned long long>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return VQA_ERR_LAUNCH;
+        }
         if (k32) hipLaunchKernelGGL(embed_sort<unsigned>, dim3(1), dim3(1024), lds, s, q, B, T, V, (int)p0, n, P, logP, w);
         else hipLaunchKernelGGL(embed_sort<unsigned long long>, dim3(1), dim3(1024), lds, s, q, B, T, V, (int)p0, n, P, logP, w);
         const dim3 grid((n + 3) / 4);

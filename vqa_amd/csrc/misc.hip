@@ -918,6 +918,7 @@ extern "C" int vqa_bce_sum(void* stream, const float* logits, const float* targe
 // acc[0] = sum_b target[b][argmax logits[b]];  rows: B floats of scratch
 extern "C" int vqa_soft_accuracy_sum(void* stream, const float* logits, const float* target, int B, int C, int ldx,
                                      float* rows, float* acc) {
+    if (B < 1 || C < 1 || ldx < C || !logits || !target || !rows || !acc) return VQA_ERR_ARG;
     hipLaunchKernelGGL(soft_acc_rows, dim3(B), dim3(64), 0, ST, logits, target, C, ldx, rows);
     hipLaunchKernelGGL(sum_f32, dim3(1), dim3(64), 0, ST, rows, B, acc);
     CHECK_LAUNCH();

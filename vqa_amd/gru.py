@@ -11,7 +11,6 @@ n_layers > 1 (gru.py:51) stacks the same recurrence: layer k reads layer k-1's o
 input-projection gradient is added to every step of the lower layer's BPTT (vqa_gru_bwd_steps' dh_seq).
 """
 import json
-import platform
 import re
 from collections import defaultdict
 
@@ -214,7 +213,6 @@ class GRU(nn.Module):
         if n_layers < 1:
             raise ValueError('n_layers must be >= 1')
         self.n_layers = n_layers
-        running_on_linux = 'Linux' in platform.platform()  # noqa: F841
         self.device = 'cuda:0' if torch.cuda.is_available() else 'cpu'
         self.train_question_path = train_question_path
         self.precision = precision

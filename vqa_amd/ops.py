@@ -72,28 +72,66 @@ def grad_dst(p):
 
 # ---- work deferred to a side stream inside a backward (head / conv weight gradients): whoever reads its results on
 # another stream joins first - the end-of-backward callback below, the data-parallel bucket hooks, Trainer.step.
-_deferred = []
+# Keyed by DEVICE and guarded by a lock: the events of one GPU are one list whatever model or thread recorded them (a
+# backward's node functions may run on an autograd worker thread while its final callbacks run on the thread that called
+# backward(), so a per-thread list would lose them).  Nothing is ever dropped while it may still be running: a reset
+# only prunes events that have completed, and a join waits for every live event of the device - joining another model's
+# deferred work as well costs a wait, never a wrong number.
+import threading
+
+_deferred = {}                      # device index -> [(event, stream, [(lo, hi) byte ranges written] or None)]
+_deferred_lock = threading.Lock()
+
+
+def _dev_key(stream=None):
+    return stream.device.index if stream is not None else torch.cuda.current_device()
 
 
 def defer_reset():
-    """Start of a backward that may defer work: forget the events of the previous pass."""
-    del _deferred[:]
+    """Start of a backward that may defer work: forget the events of earlier passes that have completed."""
+    key = _dev_key()
+    with _deferred_lock:
+        _deferred[key] = [e for e in _deferred.get(key, ()) if not e[0].query()]
 
 
-def defer_join(side):
+def defer_join(side, outputs=None):
     """Call at the end of side-stream work issued from inside a backward: records its completion and arranges for the
     stream that called .backward() to wait for it before backward() returns (autograd runs its final callbacks on
-    that stream)."""
-    _deferred.append(side.record_event())
+    that stream).  outputs: the tensors that work writes (so that a reader of some other memory need not wait)."""
+    spans = None if outputs is None else [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in outputs]
+    with _deferred_lock:
+        _deferred.setdefault(_dev_key(side), []).append((side.record_event(), side, spans))
     torch.autograd.Variable._execution_engine.queue_callback(join_deferred)
 
 
-def join_deferred():
-    """Make the current stream wait for the side-stream work deferred in this backward pass (idempotent)."""
-    if _deferred:
+def _touches(spans, lo, hi):
+    return spans is None or lo is None or any(a < hi and lo < b for a, b in spans)
+
+
+def join_deferred(lo=None, hi=None):
+    """Make the current stream wait for the side-stream work deferred on this device (idempotent); with a byte range
+    [lo, hi) only for the work that writes into it (work recorded without `outputs` always counts)."""
+    if not _deferred:               # nothing was ever deferred in this process (e.g. the CPU tests of the bucket logic)
+        return
+    with _deferred_lock:
+        live = [e for e in _deferred.get(_dev_key(), ()) if _touches(e[2], lo, hi)]
+    if live:
         cur = torch.cuda.current_stream()
-        for ev in _deferred:
+        for ev, _, _ in live:
             cur.wait_event(ev)
+
+
+def deferred_stream(lo, hi):
+    """The side stream on which the most recently deferred, still recorded work that writes into [lo, hi) runs (None
+    if there is none): a collective over those results is issued FROM that stream - ordered behind the work by the
+    stream itself - so the stream that runs the rest of the backward does not wait for it (optim.GradBuckets)."""
+    if not _deferred:
+        return None
+    with _deferred_lock:
+        for ev, stream, spans in reversed(_deferred.get(_dev_key(), ())):
+            if spans is not None and _touches(spans, lo, hi):
+                return stream
+    return None
 
 
 def dot(a, b):

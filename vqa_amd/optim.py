@@ -75,15 +75,29 @@ class FlatParams:
                 p.grad = dst.view(p.shape)
 
 
+# Data parallelism: the question encoder shares the weight-gradient stream, so that the step holds two compute streams
+# + RCCL's own - at most the 4 hardware queues a process has (GPU_MAX_HW_QUEUES) with the default stream idle: a
+# collective's kernel waits for its peers on another GPU and must never sit in a queue it shares with work a peer is
+# waiting for.  VQA_DP_FOLD_STREAMS=0 keeps the single-GPU stream layout under DP.
+DP_FOLD_STREAMS = os.environ.get('VQA_DP_FOLD_STREAMS', '1') != '0'
+# A bucket whose last gradients are produced on a side stream (the head's parameter gradients) is all-reduced FROM that
+# stream; VQA_DP_ISSUE_FROM_PRODUCER=0: the hook's stream (the critical chain) waits for the side stream instead.
+DP_ISSUE_FROM_PRODUCER = os.environ.get('VQA_DP_ISSUE_FROM_PRODUCER', '1') != '0'
+
+
 class GradBuckets:
     """Bucketed asynchronous gradient all-reduce (SUM) over torch.distributed (backend 'nccl' = RCCL on ROCm,
     'gloo' in the CPU tests)."""
 
-    def __init__(self, flat: FlatParams, group=None, force=False):
-        """force=True arms the hooks and the all-reduces even in a 1-rank group (tests: the real RCCL path on one GPU)."""
+    def __init__(self, flat: FlatParams, group=None, force=False, all_reduce=None):
+        """force=True arms the hooks and the all-reduces even in a 1-rank group (tests: the real RCCL path on one GPU).
+        all_reduce (tests): a callable buf -> handle with .wait() that stands in for the asynchronous
+        dist.all_reduce(buf, SUM) - with it the hooks are armed without a process group."""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.active = self.world > 1 or (force and dist.is_initialized())
+        self.active = self.world > 1 or (force and (dist.is_initialized() or all_reduce is not None))
+        self._all_reduce = all_reduce or (lambda buf: dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group,
+                                                                      async_op=True))
         self.pending, self.handles = [], []
         self._left = []
         if self.active:
@@ -105,15 +119,33 @@ class GradBuckets:
                 counts[b] += 1
         self._left = counts
 
+    def _launch(self, b):
+        """All-reduce bucket b.  Its gradients were written by kernels on the current stream, or by work a backward
+        deferred to a side stream (ops.defer_join names what that work writes).  In the second case the collective is
+        issued with THAT stream current - torch's process group orders its own stream behind the current one - after
+        that stream has been ordered behind this one; the current stream (the critical chain: the encoders' backward
+        comes next) does not wait for the side stream's kernels."""
+        s, e = self.flat.bucket_ranges[b]
+        buf = self.flat.grad[s:e]
+        lo = buf.data_ptr()
+        hi = lo + 4 * (e - s)
+        side = ops.deferred_stream(lo, hi) if DP_ISSUE_FROM_PRODUCER else None
+        if side is None:
+            ops.join_deferred(lo, hi)
+        self.flat.collect([q for q, bq in zip(self.flat.params, self._bucket_idx) if bq == b])
+        if side is None:
+            self.handles.append(self._all_reduce(buf))
+            return
+        side.wait_event(torch.cuda.current_stream().record_event())
+        with torch.cuda.stream(side):
+            self.handles.append(self._all_reduce(buf))
+
     def _make_hook(self, b):
         def hook(_p):
             self._left[b] -= 1
             if self._left[b] == 0:
-                ops.join_deferred()     # gradients a backward left running on a side stream (head weight gradients)
-                self.flat.collect([q for q, bq in zip(self.flat.params, self._bucket_idx) if bq == b])
-                s, e = self.flat.bucket_ranges[b]
-                self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                                    async_op=True))
+                self._launch(b)
+        hook._vqa_join_aware = True         # (_HeadFunction.backward: this hook orders itself behind the side stream)
         return hook
 
     def wait(self):
@@ -124,11 +156,7 @@ class GradBuckets:
         if self.active:
             for b, left in enumerate(self._left):
                 if left != 0:
-                    ops.join_deferred()
-                    self.flat.collect([q for q, bq in zip(self.flat.params, self._bucket_idx) if bq == b])
-                    s, e = self.flat.bucket_ranges[b]
-                    self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                                        async_op=True))
+                    self._launch(b)
         for h in self.handles:
             h.wait()
         self.reset()
@@ -170,11 +198,13 @@ class Trainer:
     """One reference training step (vqa_model.py:248-266) on the HIP path:
     zero_grad -> flip -> forward -> sum-BCE -> backward (-> bucketed all-reduce) -> clip 0.25 -> Adamax."""
 
-    def __init__(self, model, lr=2e-3, max_norm=0.25, force_buckets=False):
+    def __init__(self, model, lr=2e-3, max_norm=0.25, force_buckets=False, all_reduce=None):
         from .vqa_model import SoftScoreBCELoss
         self.model = model
         self.flat = FlatParams(model)
-        self.buckets = GradBuckets(self.flat, force=force_buckets)
+        self.buckets = GradBuckets(self.flat, force=force_buckets, all_reduce=all_reduce)
+        if self.buckets.active and DP_FOLD_STREAMS:
+            model._dp_fold_streams = True           # (a plain bool: the module still pickles whole)
         self.opt = FlatAdamax(self.flat, lr=lr, max_norm=max_norm)
         self.criterion = SoftScoreBCELoss()
 

@@ -10,7 +10,6 @@ relu(W_att [v;q] + b) = relu(W_v v + (W_q q + b)) is computed once per sample in
 region softmax / weighted sum is one kernel per sample, every linear is an MFMA GEMM with bias/ReLU fused.
 """
 import pickle
-import platform
 
 import numpy as np
 import torch
@@ -211,13 +210,19 @@ class _HeadFunction(torch.autograd.Function):
             # and a tensor hook reads g: both must see finished gradients, so this stream waits before returning.
             head_params = (g_att, v_att, b_att, g_s, v_s, g_img, v_img, b_img, g_q, v_q, b_q, g_last, v_last, b_last,
                            g_fc, v_fc)
-            adopt_only = all(p.grad is None and not p._backward_hooks for p in head_params)
+            # (post-accumulate-grad hooks read p.grad right after the adoption, on this stream: GradBuckets' own are
+            # marked join-aware - they order their collective behind the side stream themselves - any other hook, a
+            # user's, DDP's or a logger's, must find finished gradients)
+            adopt_only = all(p.grad is None and not p._backward_hooks and
+                             all(getattr(h, '_vqa_join_aware', False)
+                                 for h in (getattr(p, '_post_accumulate_grad_hooks', None) or {}).values())
+                             for p in head_params)
             with torch.cuda.stream(side):
                 wn, db_att, db_img, db_q, db_last = weights()
             for t in (dl_t, m_t, dpre_last, m0, dpv, vhat_t, dpq, q_t, dws_part, dqa, dpre_a, v_t, dqa_t, ss):
                 t.record_stream(side)                                            # (freed on this stream, read on that)
             if adopt_only:
-                ops.defer_join(side)
+                ops.defer_join(side, outputs=[x for pair in wn for x in pair] + [db_att, db_img, db_q, db_last])
             else:
                 cur.wait_event(side.record_event())
                 for t in [x for pair in wn for x in pair] + [db_att, db_img, db_q, db_last]:
@@ -234,7 +239,6 @@ class VQA(nn.Module):
                  pooling: str, activation: str, precision: str = 'bf16'):
         """Arguments as the reference (vqa_model.py:21-32); `precision` ('bf16' | 'fp32') is the only addition."""
         super(VQA, self).__init__()
-        running_on_linux = 'Linux' in platform.platform()  # noqa: F841
         self.device = 'cuda:0' if torch.cuda.is_available() else 'cpu'
         self.precision = precision
         self.cnn = cnn.CNN(padding=padding, pooling=pooling, precision=precision)
@@ -300,7 +304,9 @@ class VQA(nn.Module):
         # forward's stream, so the GRU's BPTT overlaps the CNN backward the same way.
         if SIDE_STREAM:
             cur = torch.cuda.current_stream()
-            side = _side_stream(images_batch.device)
+            # (data parallelism, optim.DP_FOLD_STREAMS: the Trainer marks the model and the question encoder shares the
+            # weight-gradient stream - two compute streams + RCCL's own)
+            side = (cnn._wgrad_stream if getattr(self, '_dp_fold_streams', False) else _side_stream)(images_batch.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 questions_representation = self.gru(questions_batch)    # [B, H]

@@ -372,7 +372,10 @@ def main():
     value = world * B * args.steps / elapsed
 
     if args.mode == 'eval':
-XX, 'value': round(value, 1), 'unit': 'samples/s',
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({'metric': 'eval samples/sec (node)', 'value': round(value, 1), 'unit': 'samples/s',
                               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                               'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
                               'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',

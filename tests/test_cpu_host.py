@@ -103,3 +103,12 @@ def test_grad_buckets_gloo_world2(tmp_path):
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'DP_OK rank0' in r.stdout and 'DP_OK rank1' in r.stdout
+
+
+def test_entry_scripts_compile():
+    """bench.py and __graft_entry__.py only run on the GPU box: a syntax error in them must show here, on the CPU."""
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ('bench.py', '__graft_entry__.py', 'tests/dp_gpu_worker.py', 'tests/dp_worker.py'):
+        py_compile.compile(os.path.join(root, name), doraise=True)

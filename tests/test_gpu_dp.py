@@ -72,8 +72,9 @@ class _FakeWork:
         torch.cuda.current_stream().wait_event(self.event)      # ProcessGroupNCCL's Work.wait(): a stream wait, no host block
 
 
-@pytest.mark.parametrize('size,tokens,hidden,batch', [(224, 14, 1024, 256), (448, 30, 2048, 64)])
-def test_bucket_stream_ordering_with_a_fake_collective(size, tokens, hidden, batch, tmp_path):
+@pytest.mark.parametrize('size,tokens,hidden,batch,fold', [(224, 14, 1024, 256, False), (224, 14, 1024, 256, True),
+                                                            (448, 30, 2048, 64, False)])
+def test_bucket_stream_ordering_with_a_fake_collective(size, tokens, hidden, batch, fold, tmp_path, monkeypatch):
     """an all-reduce over ONE rank leaves the buffer as it is whenever it runs, so the 1-rank RCCL
     tests cannot fail on a bucket that is reduced before its last writer has finished.  Here the collective is a fake
     with ProcessGroupNCCL's stream semantics that CHANGES the data: it runs on a private stream that first waits for
@@ -81,13 +82,16 @@ def test_bucket_stream_ordering_with_a_fake_collective(size, tokens, hidden, bat
     stream wait for it.  After three Trainer steps every parameter must equal, bit for bit, a non-distributed run whose
     flat gradient is doubled after a full device synchronisation: a gradient kernel (weight-gradient stream, question
     encoder's stream, the trainer's own) that lands after its bucket was "reduced" overwrites the doubled values and
-    the parameters differ.  Full bench size and the 448x448 / H = 2048 variant."""
+    the parameters differ.  Full bench size (with the question encoder on its own stream and folded onto the weight-
+    gradient stream, optim.DP_FOLD_STREAMS) and the 448x448 / H = 2048 variant."""
     import copy
     import torch
     import bench
     import vqa_model
     from vqa_amd import synth
+    from vqa_amd import optim
     from vqa_amd.optim import Trainer
+    monkeypatch.setattr(optim, 'DP_FOLD_STREAMS', fold)
     C, V = 3129, 10000
     qpath, lpath = bench.make_fixture(str(tmp_path), V, C)
     torch.manual_seed(42)
@@ -108,7 +112,7 @@ def test_bucket_stream_ordering_with_a_fake_collective(size, tokens, hidden, bat
 
     ref = Trainer(m0)
     dp = Trainer(m1, force_buckets=True, all_reduce=fake_all_reduce)
-    assert dp.buckets.active and not ref.buckets.active and m1._dp_fold_streams
+    assert dp.buckets.active and not ref.buckets.active and getattr(m1, '_dp_fold_streams', False) == fold
 
     def doubled():                                   # stands in for buckets.wait(): everything done, then g *= 2
         torch.cuda.synchronize()

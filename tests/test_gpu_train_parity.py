@@ -316,8 +316,13 @@ def test_bf16_trajectory_tracks_fp32(tmp_path):
     torch.manual_seed(42)
     base = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': H, 'n_layers': 1, 'train_question_path': qpath},
                          lpath, 256, 2, 0.0, 'max', 'relu', precision='fp32')
-    batches = [(synth.images(100 + i, B, 224).cuda(), synth.questions(100 + i, B, 14, V).cuda(),
-                synth.targets(100 + i, B, C).cuda()) for i in range(NB)]
+    batches = []
+    for i in range(NB):
+        q, t = synth.questions(100 + i, B, 14, V), synth.targets(100 + i, B, C)
+        # something to learn within 40 steps, so that the soft accuracy says more than chance: one of seven answers,
+        # chosen by the question's first word, carries the full score (VQA-v2's "yes" / "no" / "2" play this role)
+        t[torch.arange(B), q[:, 0] % 7] = 1.0
+        batches.append((synth.images(100 + i, B, 224).cuda(), q.cuda(), t.cuda()))
     ev = (torch.cat([b[0] for b in batches[:2]]), torch.cat([b[1] for b in batches[:2]]),
           torch.cat([b[2] for b in batches[:2]]))
     curves, accs, eval_loss = {}, {}, {}
@@ -347,7 +352,7 @@ def test_bf16_trajectory_tracks_fp32(tmp_path):
 
 
 # bands of test_bf16_trajectory_tracks_fp32 (measured values in DESIGN.md section 2)
-TRAJ_BAND, TRAJ_FINAL, TRAJ_ACC_DELTA, TRAJ_EVAL_LOSS = 0.25, 0.10, 0.05, 0.15
+TRAJ_BAND, TRAJ_FINAL, TRAJ_ACC_DELTA, TRAJ_EVAL_LOSS = 0.30, 0.05, 0.03, 0.06
 
 
 def test_clip_adamax_vs_torch_optim():

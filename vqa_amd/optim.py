@@ -75,11 +75,14 @@ class FlatParams:
                 p.grad = dst.view(p.shape)
 
 
-# Data parallelism: the question encoder shares the weight-gradient stream, so that the step holds two compute streams
-# + RCCL's own - at most the 4 hardware queues a process has (GPU_MAX_HW_QUEUES) with the default stream idle: a
-# collective's kernel waits for its peers on another GPU and must never sit in a queue it shares with work a peer is
-# waiting for.  VQA_DP_FOLD_STREAMS=0 keeps the single-GPU stream layout under DP.
-DP_FOLD_STREAMS = os.environ.get('VQA_DP_FOLD_STREAMS', '1') != '0'
+# Data parallelism keeps the single-GPU stream layout: the trainer's stream, the weight-gradient stream, the question
+# encoder's stream, and RCCL's own - four streams on the four hardware queues a process has (GPU_MAX_HW_QUEUES; the
+# default stream is idle during a step; profiles/r03_dp_queues.json shows the four on distinct queue ids).
+# VQA_DP_FOLD_STREAMS=1 puts the question encoder on the weight-gradient stream instead (two compute streams + RCCL's,
+# for a runtime with fewer queues): same-box A/B with one rank, bench.py --force-buckets, 4.16-4.23 ms/step plain,
+# 4.25-4.28 with the buckets armed, 4.46 folded - the recurrence's BPTT then queues in front of the conv weight
+# gradients and the end-of-backward join waits for both.
+DP_FOLD_STREAMS = os.environ.get('VQA_DP_FOLD_STREAMS', '0') != '0'
 # A bucket whose last gradients are produced on a side stream (the head's parameter gradients) is all-reduced FROM that
 # stream; VQA_DP_ISSUE_FROM_PRODUCER=0: the hook's stream (the critical chain) waits for the side stream instead.
 DP_ISSUE_FROM_PRODUCER = os.environ.get('VQA_DP_ISSUE_FROM_PRODUCER', '1') != '0'

@@ -352,7 +352,7 @@ def test_bf16_trajectory_tracks_fp32(tmp_path):
 
 
 # bands of test_bf16_trajectory_tracks_fp32 (measured values in DESIGN.md section 2)
-TRAJ_BAND, TRAJ_FINAL, TRAJ_ACC_DELTA, TRAJ_EVAL_LOSS = 0.30, 0.05, 0.03, 0.06
+TRAJ_BAND, TRAJ_FINAL, TRAJ_ACC_DELTA, TRAJ_EVAL_LOSS = 0.35, 0.05, 0.03, 0.05
 
 
 def test_clip_adamax_vs_torch_optim():

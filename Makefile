@@ -14,6 +14,8 @@ all: $(LIB)
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
+$(CSRC)/plan.o: $(CSRC)/plan_thunks.inc include/vqa_hip.h
+
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
 

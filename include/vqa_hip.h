@@ -106,7 +106,8 @@ int vqa_conv3x3_wgrad_reduce_all(void* stream, int n, const void* const* part, v
  * (unbiased variance); running_* may be NULL.  The `rows` partial rows are summed in fp64 in a fixed order. */
 int vqa_bn_finalize(void* stream, const float* part, int rows, int C, double count, const float* gamma,
                     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                    float* mean, float* invstd, float* scale, float* shift);
+                    float* mean, float* invstd, float* scale, float* shift,
+                    long* num_batches_tracked /* NULL, or the layer's int64 counter: += 1 */);
 /* eval-mode BatchNorm2d: scale / shift from the running statistics. */
 int vqa_bn_eval_coeffs(void* stream, int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift);
@@ -173,6 +174,13 @@ int vqa_wn_bwd_all(void* stream, int n, const void* const* dw, const void* const
 int vqa_cast_pad(void* stream, int src_dtype, int dst_dtype, const void* src, int M, int N, int lds, void* dst,
                  int ldd, const float* scale);
 
+/* dst [N][ldd] = src [M][lds]^T in dst_dtype, columns >= M zero: the transposed cast copy of an f32 master weight (the
+ * input gradient of nn.GRU's first projection, gru.py:51-52, multiplies by W_ih^T). */
+int vqa_cast_transpose(void* stream, int dst_dtype, const float* src, int M, int N, int lds, void* dst, int ldd);
+/* nbytes (a multiple of 4, 4-byte aligned) of zeros: the fill the step needs before a scatter (the embedding gradient,
+ * gru.py:48) without leaving the library. */
+int vqa_zero(void* stream, void* p, long nbytes);
+
 /* ---------------------------------------------------------------- question encoder (gru.py:48-52, :101-106) */
 
 /* nn.Embedding gather (gru.py:103), time-major: x[t*B + b][0..ldx) = emb[q[b][t]], zero padded; q is int64 [B][T],
@@ -219,6 +227,7 @@ int vqa_gru_bwd_steps(void* stream, int dtype, const float* dh_last, const float
  *                      packed h_t each step writes for the next one (slot 0 is never read)
  *   vqa_gru_bwd_fused  as vqa_gru_bwd_steps; dgh_p = scratch of 2 x P(3H) bf16 */
 int vqa_gru_pack_whh(void* stream, const float* w_hh, int H, void* wf, void* wb);
+/* (vqa_gru_fwd_fused writes slot 0 of h_f / h_t itself - zeros - in its first launch: the caller need not fill it) */
 int vqa_gru_fwd_fused(void* stream, const float* gi, const void* wf, const float* b_hh, float* h_f, void* h_t, void* h_p,
                       float* save, int B, int T, int H);
 int vqa_gru_bwd_fused(void* stream, const float* dh_last, const float* save, const float* h_f, const void* wb, void* dgi,
@@ -292,6 +301,19 @@ int vqa_soft_accuracy_sum_sparse(void* stream, const float* logits, const long* 
 int vqa_clip_adamax(void* stream, float* p, const float* g, float* m, float* u, long n, float max_norm, float lr,
                     float b1, float b2, float eps, int step, double* part, float* sq, float* coef,
                     float* total_norm);
+
+/* ---------------------------------------------------------------- one call for a recorded sequence of calls
+ * NO COUNTERPART IN THE REFERENCE (its layers are one Python call each: cnn.py:49-54 `self.convolutions(x)`).
+ * vqa_run_plan issues, in order, a sequence of the stream-taking entry points above that vqa_amd/plan.py recorded from
+ * one ordinary pass: words = [magic, n_ops] + per op [entry (vqa_plan_opcode(name), or -1 = "stream s waits for what
+ * stream t has been given so far"), stream index, n slots] + per slot [kind, value]: 0 int, 1 float bits, 2 double bits,
+ * 3 pointer as (base index << 48 | byte offset), 4 NULL, 5 / 6 host array of n pointers / ints (n inline words follow).
+ * bases = this call's base addresses (scratch arena, inputs, parameters, gradient buffer ...), streams = hipStream_t
+ * handles (index 0 = the caller's current stream).  Stateless: nothing is kept between calls, no allocation; an
+ * ordering point creates, records, waits for and destroys one event.  Returns 0, or the failing op's status |
+ * (1-based op index << 8); a malformed plan is status 1. */
+int vqa_plan_opcode(const char* name);
+int vqa_run_plan(const long* words, long n_words, void* const* bases, int n_bases, void* const* streams, int n_streams);
 
 /* ---------------------------------------------------------------- hardware-layout probe (tests only) */
 int vqa_probe_tr16(void* stream, const void* in, float* out);

@@ -20,7 +20,7 @@ for li, ci in enumerate(O.CONV_IDX):
     f = lambda: torch.empty(cout, device='cuda')
     mean, invstd, scale, shift = f(), f(), f(), f()
     cnt = float(y.shape[0] * y.shape[1] * y.shape[2])
-    L.lib().vqa_bn_finalize(L.stream(), L.ptr(stats), stats.shape[0], cout, ctypes.c_double(cnt), L.ptr(g), L.ptr(be), L.ptr(rm), L.ptr(rv), ctypes.c_float(0.1), ctypes.c_float(1e-5), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(shift))
+    L.lib().vqa_bn_finalize(L.stream(), L.ptr(stats), stats.shape[0], cout, ctypes.c_double(cnt), L.ptr(g), L.ptr(be), L.ptr(rm), L.ptr(rv), ctypes.c_float(0.1), ctypes.c_float(1e-5), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(shift), None)
     a = M.bn_act_pool(y, scale, shift, pool)
     ref = inter[f'cnn.act{li}']
     mine = a.float().cpu().permute(0, 3, 1, 2)

@@ -112,3 +112,18 @@ def test_entry_scripts_compile():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for name in ('bench.py', '__graft_entry__.py', 'tests/dp_gpu_worker.py', 'tests/dp_worker.py'):
         py_compile.compile(os.path.join(root, name), doraise=True)
+
+
+def test_every_stream_entry_point_has_a_plan_thunk():
+    """csrc/plan_thunks.inc is generated from include/vqa_hip.h (scripts/gen_plan_thunks.py): every entry point that
+    takes a stream must be replayable by vqa_run_plan, with the header's argument count."""
+    import ctypes
+    from vqa_amd import _lib as L
+    lib = L.lib()
+    for name, (_, argtypes) in L.declared_prototypes().items():
+        if name in ('vqa_run_plan', 'vqa_plan_opcode'):
+            continue
+        takes_stream = len(argtypes) > 0 and argtypes[0] is ctypes.c_void_p and name not in (
+            'vqa_plan_opcode',) and not name.endswith(('_rows', '_plan', '_part', '_ws_bytes'))
+        op = lib.vqa_plan_opcode(name.encode())
+        assert (op >= 0) == takes_stream, name

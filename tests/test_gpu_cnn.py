@@ -171,10 +171,9 @@ def test_bn_relu_pool_fwd_bwd(prec, tol, pool, C, H, W):
     rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
     n = float(B * H * W)
     gd, bd = gamma.cuda(), beta.cuda()      # keep the device copies alive across the asynchronous launch
-    L.check(L.lib().vqa_bn_finalize(L.stream(), L.ptr(part), 1, C, ctypes.c_double(n), L.ptr(gd),
-                                    L.ptr(bd), L.ptr(rm), L.ptr(rv), ctypes.c_float(0.1),
-                                    ctypes.c_float(1e-5), L.ptr(mean_d), L.ptr(invstd), L.ptr(scale), L.ptr(shift)),
-            'bn_finalize')
+    nbt = torch.full((), 6, device='cuda', dtype=torch.int64)
+    L.call('vqa_bn_finalize', part, 1, C, n, gd, bd, rm, rv, 0.1, 1e-5, mean_d, invstd, scale, shift, nbt)
+    assert int(nbt) == 7                                    # num_batches_tracked is bumped by the statistics kernel
     assert torch.allclose(mean_d.cpu(), mean, atol=1e-5)
     assert torch.allclose(rv.cpu(), 0.9 + 0.1 * var * n / (n - 1), rtol=1e-4)
     a = M.bn_act_pool(yd, scale, shift, pool)
@@ -223,7 +222,8 @@ def test_conv_block_fwd_bwd(prec, tol, cin, cout, S, pad, pool):
     dev = lambda t: t.cuda()
     rm, rv = torch.zeros(cout, device='cuda'), torch.ones(cout, device='cuda')
     a, saved = M.block_fwd(_nhwc(x, dt), dev(w), dev(b), dev(gamma), dev(beta), rm, rv, pad, pool, True)
-    dx, dw, db, dg, dbt, _ = M.block_bwd(_nhwc(da, dt), saved, dev(w), cin, pad, pool, True)
+    dw, dg, dbt = torch.empty(cout, cin, 3, 3, device='cuda'), torch.empty(cout, device='cuda'), torch.empty(cout, device='cuda')
+    dx, _ = M.block_bwd(_nhwc(da, dt), saved, dev(w), cin, pad, pool, True, (dw, dg, dbt))
     rel = lambda u, v: float((u.double().cpu() - v.double()).norm() / v.double().norm())
     assert rel(a.float().permute(0, 3, 1, 2), a_ref.detach()) < tol
     assert rel(dg, gr.grad) < tol and rel(dbt, br.grad) < tol

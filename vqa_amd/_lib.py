@@ -57,18 +57,33 @@ def check(status, what):
 
 
 _FN = {}
+_REC = None             # plan.Recorder of the pass being recorded (vqa_amd/plan.py), or None
+
+
+def _conv(a):
+    if isinstance(a, torch.Tensor):
+        return a.data_ptr()
+    if isinstance(a, (list, tuple)):            # a HOST array argument: n ints, or n device pointers (tensors / None)
+        if a and all(isinstance(v, int) for v in a):
+            return (ctypes.c_int * len(a))(*a)
+        return (ctypes.c_void_p * len(a))(*[None if v is None else v.data_ptr() for v in a])
+    return a
 
 
 def call(name, *args):
-    """Call an exported function: tensors -> device pointers, ints/floats passed by value, stream prepended.
-    The ctypes prototypes are the declarations of include/vqa_hip.h (declared_prototypes(), set when the library is
-    loaded), so every argument is converted to the declared C type whatever Python type a call site passes."""
+    """Call an exported function: tensors -> device pointers, lists -> host arrays, ints/floats passed by value, stream
+    prepended.  The ctypes prototypes are the declarations of include/vqa_hip.h (declared_prototypes(), set when the
+    library is loaded), so every argument is converted to the declared C type whatever Python type a call site passes.
+    While a plan is being recorded (vqa_amd/plan.py) every successful call is appended to it."""
     fn = _FN.get(name)
     if fn is None:
         fn = _FN[name] = getattr(lib(), name)
-    status = fn(_raw_stream(), *[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args])
+    raw = _raw_stream()
+    status = fn(raw, *[_conv(a) for a in args])
     if status != 0:
         raise VqaHipError(f'{name} failed with status {status}', status)
+    if _REC is not None:
+        _REC.op(name, raw, args)
 
 
 def fits(name, *args, **kw):

@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
+from . import plan as P
 
 CHANNELS = [3, 16, 16, 32, 32, 64, 64, 128, 128, 256, 256]      # reference cnn.py:23-40
 CONV_IDX = [0, 3, 7, 10, 14, 17, 21, 24, 28, 31]
@@ -60,7 +61,7 @@ def pack_weights(w, cin_p, dtype, dgrad):
     rows = cin_p if dgrad else cout
     ck = _ck(red, dtype)
     kp = _kp(ck, dtype)
-    out = torch.empty((red // ck) * rows * kp, device=w.device, dtype=dtype)
+    out = P.empty(((red // ck) * rows * kp,), dtype, w.device)
     L.call('vqa_conv_pack', L.dt(out), w, out, cout, cin, cin_p, ck, kp, int(dgrad))
     return out
 
@@ -70,7 +71,6 @@ def pack_all(jobs, dtype, scales=None):
     scales[i] (optional, forward jobs) = per-output-channel factor folded into slab i (eval-mode BatchNorm)."""
     if not jobs:
         return []
-    ct = L.ctypes
     desc, sizes = [], []
     for w, cin_p, dgrad in jobs:
         cout, cin = w.shape[0], w.shape[1]
@@ -79,17 +79,14 @@ def pack_all(jobs, dtype, scales=None):
         kp = _kp(ck, dtype)
         desc += [cout, cin, cin_p, ck, kp, int(dgrad)]
         sizes.append(-(-(red // ck) * rows * kp // 64) * 64)          # 128-byte aligned slices
-    buf = torch.empty(sum(sizes), device=jobs[0][0].device, dtype=dtype)
+    buf = P.empty((sum(sizes),), dtype, jobs[0][0].device)
     outs, off = [], 0
     for n in sizes:
         outs.append(buf[off:off + n])
         off += n
     n = len(jobs)
-    L.check(L.lib().vqa_conv_pack_all(L.stream(), L.dt(buf), n, (ct.c_void_p * n)(*[j[0].data_ptr() for j in jobs]),
-                                      (ct.c_void_p * n)(*[o.data_ptr() for o in outs]), (ct.c_int * (6 * n))(*desc),
-                                      None if scales is None else
-                                      (ct.c_void_p * n)(*[None if t is None else t.data_ptr() for t in scales])),
-            'vqa_conv_pack_all')
+    L.call('vqa_conv_pack_all', L.dt(buf), n, [j[0] for j in jobs], outs, desc,
+           None if scales is None else list(scales))
     return outs
 
 
@@ -113,11 +110,11 @@ def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', rel
     B, IH, IW, cin = x.shape
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
     R, CW = pick_tile(OH, OW)
-    y = torch.empty(B, OH, OW, cout, device=x.device, dtype=x.dtype) if out is None else out
+    y = P.empty((B, OH, OW, cout), x.dtype, x.device) if out is None else out
     G = _plan(L.dt(x), B, IH, IW, cin, OH, OW, cout, pad, R, CW, 1 if in_coeffs is not None else (2 if bst else 0))
     stats = None
     if want_stats or bst:       # (out / stats_out: a batch slice of a larger call writes its part of the whole)
-        stats = torch.empty(G, cout, 2, device=x.device, dtype=torch.float32) if stats_out is None else stats_out
+        stats = P.empty((G, cout, 2), torch.float32, x.device) if stats_out is None else stats_out
         assert stats.shape[0] == G and stats.is_contiguous()
     assert y.is_contiguous() and tuple(y.shape) == (B, OH, OW, cout)
     cr = cin if cin_real is None else cin_real
@@ -190,8 +187,8 @@ def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None, defer=None, part_
         L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part_out, None, G, B, IH, IW, cin, cin_real,
                OH, OW, cout, pad, R, CW, isc, ish, tag=tag)
         return None
-    part = torch.empty(G, cout, 9, cin, device=x.device, dtype=torch.float32)
-    dw = out if out is not None else torch.empty(cout, cin_real, 3, 3, device=x.device, dtype=torch.float32)
+    part = P.empty((G, cout, 9, cin), torch.float32, x.device)
+    dw = out if out is not None else P.empty((cout, cin_real, 3, 3), torch.float32, x.device)
     tag = lambda: _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4)
     L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw if defer is None else None, G, B, IH, IW, cin, cin_real,
            OH, OW, cout, pad, R, CW, isc, ish, tag=tag)
@@ -204,23 +201,22 @@ def wgrad_reduce_all(jobs):
     """The deferred reductions of conv_wgrad(defer=jobs), one launch."""
     if not jobs:
         return
-    ct, n = L.ctypes, len(jobs)
     desc = []
     for _, _, G, cout, cin, cin_real in jobs:
         desc += [G, cout, cin, cin_real]
-    L.check(L.lib().vqa_conv3x3_wgrad_reduce_all(L.stream(), n, (ct.c_void_p * n)(*[j[0].data_ptr() for j in jobs]),
-                                                 (ct.c_void_p * n)(*[j[1].data_ptr() for j in jobs]),
-                                                 (ct.c_int * (4 * n))(*desc)), 'vqa_conv3x3_wgrad_reduce_all')
+    L.call('vqa_conv3x3_wgrad_reduce_all', len(jobs), [j[0] for j in jobs], [j[1] for j in jobs], desc)
 
 
-def bn_act_pool(y, scale, shift, pool, want_ysel=False):
+def bn_act_pool(y, scale, shift, pool, want_ysel=False, out=None):
     """a = pool(relu(scale * y + shift)).  want_ysel (max pool): returns (a, ysel), ysel = the raw y at the selected
-    position of every window (None when the shape is not served - the caller then runs the reduce pass)."""
+    position of every window (None when the shape is not served - the caller then runs the reduce pass).
+    out: the tensor a is written to (same dtype as y)."""
     B, H, W, C = y.shape
-    a = torch.empty(B, H // 2 if pool else H, W // 2 if pool else W, C, device=y.device, dtype=y.dtype)
+    ashape = (B, H // 2 if pool else H, W // 2 if pool else W, C)
+    a = P.empty(ashape, y.dtype, y.device) if out is None else out.view(ashape)
     tag = lambda: dict(kind='fwd', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((y.numel() + a.numel()) * y.element_size()))
     if want_ysel and pool == 1:
-        ysel = torch.empty_like(a)
+        ysel = P.empty(ashape, y.dtype, y.device)
         tag2 = lambda: dict(tag(), bytes=tag()['bytes'] + a.numel() * y.element_size())
         if L.fits('vqa_bn_act_pool_fwd', L.dt(y), y, a, scale, shift, B, H, W, C, pool, ysel, tag=tag2):
             return a, ysel
@@ -230,8 +226,8 @@ def bn_act_pool(y, scale, shift, pool, want_ysel=False):
 
 def to_nhwc(images, dtype):
     B, C, H, W = images.shape
-    out = torch.empty(B, H, W, CIN0_PAD, device=images.device, dtype=dtype)
-    L.call('vqa_nchw_to_nhwc', L.dt(images), L.dt(out), images.contiguous(), out, B, C, H, W, CIN0_PAD)
+    out = P.empty((B, H, W, CIN0_PAD), dtype, images.device)
+    L.call('vqa_nchw_to_nhwc', L.dt(images), L.dt(out), images, out, B, C, H, W, CIN0_PAD)
     return out
 
 
@@ -265,9 +261,9 @@ def first_fwd(images, w, bias, pad, want_stats, wscale=None, relu=False, mirror=
     B, _, IH, IW = images.shape
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
     R, CW = pick_first_tile(OH, OW)
-    y = torch.empty(B, OH, OW, 16, device=images.device, dtype=torch.bfloat16)
+    y = P.empty((B, OH, OW, 16), torch.bfloat16, images.device)
     G = min(B * (-(-OH // R)) * (-(-OW // CW)), 256 * (5 - FIRST_RESERVE))   # persistent workgroups: 5 resident per CU (92 VGPRs)
-    stats = torch.empty(G, 16, 2, device=images.device, dtype=torch.float32) if want_stats else None
+    stats = P.empty((G, 16, 2), torch.float32, images.device) if want_stats else None
     tag = lambda: dict(kind='first', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
                bytes=float(images.numel() * images.element_size() + y.numel() * 2 + w.numel() * 4))
     L.call('vqa_conv3x3_first_fwd', L.dt(images), images, w, y, bias, stats, B, IH, IW, OH, OW, pad, R, CW, G,
@@ -284,8 +280,8 @@ def first_wgrad(images, dy, pad, out=None, mirror=False, bn=None):
     tiles = B * (-(-OH // R)) * (-(-OW // CW))
     # persistent workgroups: what is resident per CU (84 VGPRs -> 5 waves per SIMD; the fused kernel has 112 -> 4)
     G = min(tiles, 256 * ((4 if bn is not None else 5) - FIRST_RESERVE))
-    part = torch.empty(G, 16, 32, device=dy.device, dtype=torch.float32)
-    dw = out if out is not None else torch.empty(16, 3, 3, 3, device=dy.device, dtype=torch.float32)
+    part = P.empty((G, 16, 32), torch.float32, dy.device)
+    dw = out if out is not None else P.empty((16, 3, 3, 3), torch.float32, dy.device)
     tag = lambda: dict(kind='first_wgrad', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
                bytes=float(images.numel() * images.element_size() + dy.numel() * 2))
     if bn is not None:
@@ -300,11 +296,12 @@ def first_wgrad(images, dy, pad, out=None, mirror=False, bn=None):
 
 
 def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False, wpk=None, mirror=False,
-              in_coeffs=None, apply=True, want_ysel=False):
+              in_coeffs=None, apply=True, want_ysel=False, nbt=None, out=None):
     """conv3x3 -> BatchNorm -> ReLU -> (pool).  x NHWC (first=True: the NCHW image, dedicated kernel).  Returns
     (a, saved) with saved = (x, y, scale, shift, mean, invstd) for block_bwd.
     in_coeffs: x is the raw conv output of the previous block, whose BatchNorm + ReLU this block's conv applies itself.
-    apply=False (pool == 0 only): the BatchNorm + ReLU pass is left to the consumer; returns a = None."""
+    apply=False (pool == 0 only): the BatchNorm + ReLU pass is left to the consumer; returns a = None.
+    nbt: the layer's num_batches_tracked counter (bumped by the statistics kernel); out: where `a` is written."""
     dev, cout = x.device, w.shape[0]
     if first:
         y, stats = first_fwd(x, w, bias, pad, training, mirror=mirror)
@@ -312,20 +309,17 @@ def block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, training, first=False,
         if wpk is None:
             wpk = pack_weights(w, x.shape[3], x.dtype, dgrad=False)
         y, stats = conv_fwd(x, wpk, bias, cout, pad, training, cin_real=w.shape[1], in_coeffs=in_coeffs)
-    scale, shift, mean, invstd = torch.empty(4, cout, device=dev, dtype=torch.float32).unbind(0)   # ONE [4,C] block
+    scale, shift, mean, invstd = P.empty((4, cout), torch.float32, dev).unbind(0)   # ONE [4,C] block
     if training:
         count = float(y.shape[0] * y.shape[1] * y.shape[2])
-        L.check(L.lib().vqa_bn_finalize(L.stream(), L.ptr(stats), stats.shape[0], cout, L.ctypes.c_double(count),
-                                        L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv),
-                                        L.ctypes.c_float(BN_MOMENTUM), L.ctypes.c_float(BN_EPS), L.ptr(mean),
-                                        L.ptr(invstd), L.ptr(scale), L.ptr(shift)),
-                'vqa_bn_finalize')
+        L.call('vqa_bn_finalize', stats, stats.shape[0], cout, count, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, mean,
+               invstd, scale, shift, nbt)
     else:
         L.call('vqa_bn_eval_coeffs', cout, gamma, beta, rm, rv, BN_EPS, scale, shift)
     if want_ysel:
         a, ysel = bn_act_pool(y, scale, shift, pool, want_ysel=True)
         return a, (x, y, scale, shift, mean, invstd), ysel
-    a = bn_act_pool(y, scale, shift, pool) if apply else None
+    a = bn_act_pool(y, scale, shift, pool, out=out) if apply else None
     return a, (x, y, scale, shift, mean, invstd)
 
 
@@ -336,9 +330,13 @@ def coef_block(scale, shift, mean, invstd):
     return scale.as_strided((4, C), (C, 1))
 
 
-def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None, params=None, mirror=False,
+def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, gdst, first=False, wpk_d=None, mirror=False,
               side=None, in_coeffs=None, part=None, bst=None, defer=None):
-    """d = gradient w.r.t. the block output (NHWC, activation dtype).  Returns (dx, dw, dbias, dgamma, dbeta, below).
+    """d = gradient w.r.t. the block output (NHWC, activation dtype).  gdst = (dw, dgamma, dbeta): where the layer's
+    parameter gradients are written (slots of the flat gradient buffer, or of the pass's own gradient block; the conv
+    bias feeds a training-mode BatchNorm, so its gradient is identically zero - the reference produces rounding noise
+    ~1e-7 of the weight-gradient scale there - and its slot is never written: zero from the buffer's fill).
+    Returns (dx, below).
     side: HIP stream for the weight gradient (off the dgrad -> BatchNorm-backward chain), None = current stream.
     part: this block's BatchNorm-backward partial sums, already produced by the data gradient of the block above.
     bst = (y, coef) of the block BELOW: this block's data gradient also produces that block's partial sums (`below`)."""
@@ -349,38 +347,29 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
     have_part = part is not None
     if not have_part:
         rows = L.lib().vqa_bn_bwd_rows(L.dt(y), B, H, W, C, pool)
-        part = torch.empty(rows, C, 2, device=dev, dtype=torch.float32)
+        part = P.empty((rows, C, 2), torch.float32, dev)
     rows = part.shape[0]
-    # gradients go straight into the flat gradient buffer when the parameters live in one (ops.grad_dst)
-    _, pb, pg, pbt = params if params is not None else (None, None, None, None)
-    dw_out = ops.grad_dst(w)
-    dbias, dgamma, dbeta = (ops.grad_dst(t) if t is not None else None for t in (pb, pg, pbt))
-    if dgamma is None:
-        dgamma = torch.empty(C, device=dev, dtype=torch.float32)
-    if dbeta is None:
-        dbeta = torch.empty(C, device=dev, dtype=torch.float32)
-    c1, c2 = torch.empty(2, C, device=dev, dtype=torch.float32).unbind(0)
+    dw_out, dgamma, dbeta = gdst
+    c1, c2 = P.empty((2, C), torch.float32, dev).unbind(0)
     es = y.element_size()
     if not have_part:
         tag = lambda: dict(kind='reduce', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((y.numel() + d.numel()) * es))
         L.call('vqa_bn_bwd', L.dt(y), 0, y, d, None, scale, shift, mean, invstd, None, None, part, B, H, W, C, pool,
                tag=tag)
-    L.check(L.lib().vqa_bn_bwd_finalize(L.stream(), L.ptr(part), rows, C, L.ctypes.c_double(count), L.ptr(dgamma),
-                                        L.ptr(dbeta), L.ptr(c1), L.ptr(c2)), 'vqa_bn_bwd_finalize')
+    L.call('vqa_bn_bwd_finalize', part, rows, C, count, dgamma, dbeta, c1, c2)
+    cur = torch.cuda.current_stream()
     if first and pool == 0 and not need_dx and FUSE_FIRST_BN:
         # layer 1: nobody but its weight gradient reads dy - the apply pass runs inside that kernel, dy is never stored
-        bn = (d.contiguous(), scale, shift, mean, invstd, c1, c2)
+        bn = (d, scale, shift, mean, invstd, c1, c2)
         if side is None or FIRST_WGRAD_MAIN:
-            dw = first_wgrad(x, y, pad, out=dw_out, mirror=mirror, bn=bn)
+            first_wgrad(x, y, pad, out=dw_out, mirror=mirror, bn=bn)
         else:
-            side.wait_event(torch.cuda.current_stream().record_event())
+            P.stream_wait(side, cur)
             with torch.cuda.stream(side):
-                dw = first_wgrad(x, y, pad, out=dw_out, mirror=mirror, bn=bn)
+                first_wgrad(x, y, pad, out=dw_out, mirror=mirror, bn=bn)
             for t in (x, y, bn[0], scale, c1, part):
                 t.record_stream(side)
-        if dbias is None:
-            dbias = torch.zeros(C, device=dev, dtype=torch.float32)
-        return None, dw, dbias, dgamma, dbeta, None
+        return None, None
     S = _bwd_slices(B, y.numel() * es)
     if S > 1 and not first and need_dx and defer is None:
         # Batch slices: apply pass -> weight gradient -> data gradient per B / S images, so that the slice's dy (and
@@ -390,15 +379,13 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
         # (205 MB tensors, which fit the cache whole) +0.4 %.
         Bs = B // S
         wd = wpk_d if wpk_d is not None else pack_weights(w, x.shape[3], x.dtype, dgrad=True)
-        dx = torch.empty_like(x)
-        dys = torch.empty_like(y)
+        dx = P.empty(tuple(x.shape), x.dtype, dev)
+        dys = P.empty(tuple(y.shape), y.dtype, dev)
         IH, IW, cin = x.shape[1], x.shape[2], x.shape[3]
         gd = _plan(L.dt(y), Bs, H, W, C, IH, IW, cin, 2 - pad, *pick_tile(IH, IW), 2 if bst else 0)
-        below = torch.empty(S * gd, cin, 2, device=dev, dtype=torch.float32) if bst else None
+        below = P.empty((S * gd, cin, 2), torch.float32, dev) if bst else None
         gw = wgrad_rows(x[:Bs], dys[:Bs])
-        part_w = torch.empty(S * gw, C, 9, cin, device=dev, dtype=torch.float32)
-        dw = dw_out if dw_out is not None else torch.empty(C, cin_real, 3, 3, device=dev, dtype=torch.float32)
-        cur = torch.cuda.current_stream()
+        part_w = P.empty((S * gw, C, 9, cin), torch.float32, dev)
         for si in range(S):
             sl = slice(si * Bs, (si + 1) * Bs)
             tag = lambda sl=sl: dict(kind='apply', shape=f'{H}x{W}x{C}', flops=0.0,
@@ -406,26 +393,27 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
             L.call('vqa_bn_bwd', L.dt(y), 1, y[sl], d[sl], dys[sl], scale, shift, mean, invstd, c1, c2, None, Bs, H, W,
                    C, pool, tag=tag)
             if side is not None:
-                side.wait_event(cur.record_event())
+                P.stream_wait(side, cur)
             with torch.cuda.stream(side if side is not None else cur):
                 conv_wgrad(x[sl], dys[sl], cin_real, pad, in_coeffs=in_coeffs, part_out=part_w[si * gw:(si + 1) * gw])
             conv_fwd(dys[sl], wd, None, cin, 2 - pad, False, kind='dgrad',
                      bst=(bst[0][sl], bst[1]) if bst else None, out=dx[sl],
                      stats_out=below[si * gd:(si + 1) * gd] if bst else None)
         with torch.cuda.stream(side if side is not None else cur):
-            wgrad_reduce_all([(part_w, dw, S * gw, C, cin, cin_real)])
+            wgrad_reduce_all([(part_w, dw_out, S * gw, C, cin, cin_real)])
         if side is not None:
             for t in (dys, x, part_w):
                 t.record_stream(side)
-        if dbias is None:
-            dbias = torch.zeros(C, device=dev, dtype=torch.float32)
-        return dx, dw, dbias, dgamma, dbeta, below
-    dy = torch.empty_like(y)
+        return dx, below
+    dy = P.empty(tuple(y.shape), y.dtype, dev)
     tag = lambda: dict(kind='apply', shape=f'{H}x{W}x{C}', flops=0.0, bytes=float((2 * y.numel() + d.numel()) * es))
     L.call('vqa_bn_bwd', L.dt(y), 1, y, d, dy, scale, shift, mean, invstd, c1, c2, None, B, H, W, C, pool, tag=tag)
+
     def wgrad():
-        return (first_wgrad(x, dy, pad, out=dw_out, mirror=mirror) if first
-                else conv_wgrad(x, dy, cin_real, pad, out=dw_out, in_coeffs=in_coeffs, defer=defer))
+        if first:
+            first_wgrad(x, dy, pad, out=dw_out, mirror=mirror)
+        else:
+            conv_wgrad(x, dy, cin_real, pad, out=dw_out, in_coeffs=in_coeffs, defer=defer)
 
     def dgrad():
         if not need_dx:
@@ -434,22 +422,17 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, first=False, wpk_d=None
         return conv_fwd(dy, wd, None, x.shape[3], 2 - pad, False, kind='dgrad', bst=bst)
 
     if side is None:
-        dw = wgrad()
+        wgrad()
         dx, below = dgrad()
     else:
         # (enqueueing the data gradient first instead measured the same)
-        side.wait_event(torch.cuda.current_stream().record_event())
+        P.stream_wait(side, cur)
         with torch.cuda.stream(side):
-            dw = wgrad()
+            wgrad()
         dy.record_stream(side)
         x.record_stream(side)
         dx, below = dgrad()
-    # the conv bias feeds a training-mode BatchNorm: its gradient is identically zero (the reference produces
-    # rounding noise ~1e-7 of the weight-gradient scale here)
-    # (its slot in the flat gradient buffer is never written: zero from FlatParams' initial fill)
-    if dbias is None:
-        dbias = torch.zeros(C, device=dev, dtype=torch.float32)
-    return dx, dw, dbias, dgamma, dbeta, below
+    return dx, below
 
 
 _POOL_ID = {}
@@ -555,8 +538,116 @@ def _wgrad_stream(dev):
     return _WGRAD_STREAMS[key]
 
 
+def _knobs():
+    """Everything in this module the recorded launch sequence depends on (part of every plan key)."""
+    return (WGRAD_STREAM, FUSE_BN_FWD, FUSE_BN_BWD, FUSE_FIRST_BN, FUSE_POOL_BWD, DEFER_WGRAD_REDUCE, BWD_SLICES,
+            BWD_SLICE_MIN_MB, WGRAD_RESERVE, FIRST_WGRAD_MAIN, FIRST_RESERVE)
+
+
+def out_regions(size, padding):
+    """Side of the final feature map for a `size` x `size` image (cnn.py:22-42: five blocks of conv(pad) conv(0) pool)."""
+    for li in range(10):
+        size = size + 2 * (padding if li in (0, 2, 4, 6) else 0) - 2
+        if li % 2 == 1:
+            size //= 2
+    return size
+
+
+def _grad_layout():
+    """Element offsets of the 40 parameter gradients in the pass's own gradient block (no flat buffer to write into):
+    every gradient starts on a 256-byte boundary."""
+    offs, off = [], 0
+    for li in range(10):
+        for n in (CHANNELS[li + 1] * CHANNELS[li] * 9, CHANNELS[li + 1], CHANNELS[li + 1], CHANNELS[li + 1]):
+            offs.append(off)
+            off += -(-n // 64) * 64
+    return offs, off
+
+
+def _train_forward(images, first, params, buffers, padding, pool_mode, dtype, mirror, out):
+    """The training forward, launch by launch (recorded into a plan when one is being made).  Writes the [B,k,256] f32
+    output into `out`; returns (saved, meta, ysels, wd)."""
+    x = images if first else to_nhwc(images, dtype)
+    saved, meta, ysels = [], [], [None] * 10
+    # every packed weight slab of the step (forward and data-gradient) in one launch
+    cinp = [CIN0_PAD] + list(CHANNELS[1:10])
+    fjobs = [(params[4 * li], cinp[li], False) for li in range(10) if not (first and li == 0)]
+    djobs = [(params[4 * li], cinp[li], True) for li in range(1, 10)]
+    slabs = pack_all(fjobs + djobs, dtype)
+    wf = ([None] if first else []) + slabs[:len(fjobs)]
+    wd = [None] + slabs[len(fjobs):]
+    in_coeffs = None
+    for li in range(10):
+        w, bias, gamma, beta = params[4 * li: 4 * li + 4]
+        rm, rv, nbt = buffers[3 * li: 3 * li + 3]
+        pad = padding if li in (0, 2, 4, 6) else 0
+        pool = pool_mode if li % 2 == 1 else 0
+        defer = FUSE_BN_FWD and pool == 0 and li < 9        # the next conv (pad 0) applies this block's BN + ReLU
+        # (the pooled layer's channels are the output channels of the data gradient above it)
+        ysel_ok = pool == 1 and li < 9 and CHANNELS[li + 1] <= FUSE_POOL_BWD
+        # the last block's output IS the encoder's output: f32 [B,k,256] (cnn.py:52-53) - written in place on the f32
+        # path, converted by one more launch on the bf16 path
+        last_out = out if (li == 9 and dtype == torch.float32) else None
+        if ysel_ok:
+            a, sv, ysels[li] = block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, True, first=first and li == 0,
+                                         wpk=wf[li], mirror=mirror and li == 0, in_coeffs=in_coeffs, want_ysel=True,
+                                         nbt=nbt)
+        else:
+            a, sv = block_fwd(x, w, bias, gamma, beta, rm, rv, pad, pool, True, first=first and li == 0, wpk=wf[li],
+                              mirror=mirror and li == 0, in_coeffs=in_coeffs, apply=not defer, nbt=nbt, out=last_out)
+        saved += list(sv)
+        meta.append((pad, pool, in_coeffs is not None))
+        x, in_coeffs = (sv[1], (sv[2], sv[3])) if defer else (a, None)
+    if dtype != torch.float32:
+        B, PH, PW, C = x.shape
+        L.call('vqa_cast_pad', L.dt(x), L.F32, x, B * PH * PW, C, C, out, C, None)
+    return saved, meta, ysels, wd
+
+
+def _train_backward(dout, saved, ysels, wd, meta, gdsts, dtype, first, mirror):
+    """The training backward, launch by launch.  dout f32 [B,k,256] contiguous; gdsts[4 li + j] = where layer li's
+    (weight, bias, gamma, beta) gradient goes."""
+    B, H, W, C = saved[55].shape
+    pool_last = meta[9][1]
+    PH, PW = (H // 2, W // 2) if pool_last else (H, W)
+    if dtype == torch.float32:
+        d = dout.view(B, PH, PW, C)
+    else:
+        d = P.empty((B, PH, PW, C), dtype, dout.device)
+        L.call('vqa_cast_pad', L.F32, L.dt(d), dout, B * PH * PW, C, C, d, C, None)
+    side = _wgrad_stream(dout.device) if WGRAD_STREAM else None
+    part = None
+    deferred = [] if DEFER_WGRAD_REDUCE else None      # weight-gradient slabs, reduced by one launch at the end
+    for li in range(9, -1, -1):
+        pad, pool, fused_in = meta[li]
+        # the block below has no pool: this block's data gradient can also do its BatchNorm-backward reduction
+        bst = None
+        if li > 0 and meta[li - 1][1] == 0 and CHANNELS[li] <= min(FUSE_BN_BWD, _ck(CHANNELS[li], dtype)):
+            bst = (saved[6 * (li - 1) + 1], coef_block(*saved[6 * (li - 1) + 2: 6 * (li - 1) + 6]))
+        elif ysels.get(li - 1) is not None:       # max-pooled block below: the same sums from (d, ysel) at pooled resolution
+            bst = (ysels[li - 1], coef_block(*saved[6 * (li - 1) + 2: 6 * (li - 1) + 6]))
+        # fused_in: this layer's input x is the previous layer's raw conv output; its weight gradient re-applies
+        # that layer's BatchNorm + ReLU (saved scale / shift) as the forward conv did
+        in_coeffs = (saved[6 * (li - 1) + 2], saved[6 * (li - 1) + 3]) if fused_in else None
+        g = gdsts[4 * li: 4 * li + 4]
+        d, part = block_bwd(d, saved[6 * li: 6 * li + 6], None, CHANNELS[li], pad, pool, li > 0, (g[0], g[2], g[3]),
+                            first=first and li == 0, wpk_d=wd[li], mirror=mirror and li == 0, side=side,
+                            in_coeffs=in_coeffs, part=part, bst=bst, defer=deferred)
+    if side is not None:
+        with torch.cuda.stream(side):
+            wgrad_reduce_all(deferred)
+        P.stream_wait(torch.cuda.current_stream(), side)
+    else:
+        wgrad_reduce_all(deferred)
+
+
 class _CnnFunction(torch.autograd.Function):
-    """images [B,3,S,S] + the 40 parameters + 20 running buffers -> [B,k,256] fp32."""
+    """images [B,3,S,S] + the 40 parameters + 30 buffers (running_mean, running_var, num_batches_tracked per layer)
+    -> [B,k,256] fp32.
+
+    Training passes run from PLANS (vqa_amd/plan.py): the first pass of a shape runs launch by launch and is recorded;
+    every later one allocates one scratch arena and makes one C-ABI call (vqa_run_plan) for the forward and one for the
+    backward - the same launches with the same arguments on the same streams."""
 
     @staticmethod
     def forward(ctx, images, cfg, *tensors):
@@ -566,81 +657,136 @@ class _CnnFunction(torch.autograd.Function):
         if mirror and not (first and training):
             # the mirrored read lives in the first-layer training kernels; everywhere else flip the batch itself
             images, mirror = images.flip(-1), False
-        x = images.contiguous() if first else to_nhwc(images, dtype)
+        images = images.contiguous()
+        dev = images.device
         if not training:
             ctx.cfg = cfg
-            return _eval_forward(x, first, params, buffers, padding, pool_mode, dtype)
-        saved, meta, ysels = [], [], [None] * 10
-        # every packed weight slab of the step (forward, and data-gradient when training) in one launch
-        cinp = [CIN0_PAD] + list(CHANNELS[1:10])
-        fjobs = [(params[4 * li], cinp[li], False) for li in range(10) if not (first and li == 0)]
-        djobs = [(params[4 * li], cinp[li], True) for li in range(1, 10)] if training else []
-        slabs = pack_all(fjobs + djobs, dtype)
-        wf = ([None] if first else []) + slabs[:len(fjobs)]
-        ctx.wd = [None] + slabs[len(fjobs):] if training else None
-        in_coeffs = None
-        for li in range(10):
-            w, bias, gamma, beta = params[4 * li: 4 * li + 4]
-            pad = padding if li in (0, 2, 4, 6) else 0
-            pool = pool_mode if li % 2 == 1 else 0
-            defer = FUSE_BN_FWD and pool == 0 and li < 9        # the next conv (pad 0) applies this block's BN + ReLU
-            # (the pooled layer's channels are the output channels of the data gradient above it)
-            ysel_ok = pool == 1 and li < 9 and CHANNELS[li + 1] <= FUSE_POOL_BWD
-            if ysel_ok:
-                a, sv, ysels[li] = block_fwd(x, w, bias, gamma, beta, buffers[2 * li], buffers[2 * li + 1], pad, pool,
-                                             training, first=first and li == 0, wpk=wf[li], mirror=mirror and li == 0,
-                                             in_coeffs=in_coeffs, want_ysel=True)
-            else:
-                a, sv = block_fwd(x, w, bias, gamma, beta, buffers[2 * li], buffers[2 * li + 1], pad, pool, training,
-                                  first=first and li == 0, wpk=wf[li], mirror=mirror and li == 0, in_coeffs=in_coeffs,
-                                  apply=not defer)
-            saved += list(sv)
-            meta.append((pad, pool, in_coeffs is not None))
-            x, in_coeffs = (sv[1], (sv[2], sv[3])) if defer else (a, None)
+            return _eval_forward(images if first else to_nhwc(images, dtype), first, params,
+                                 [b for i, b in enumerate(buffers) if i % 3 != 2], padding, pool_mode, dtype)
+        B, _, IH, IW = images.shape
+        ko = out_regions(IH, padding) * out_regions(IW, padding)
+        out = torch.empty(B, ko, 256, device=dev, dtype=torch.float32)
+        key = ('cnn.fwd', tuple(images.shape), images.dtype, padding, pool_mode, dtype, mirror, first, _knobs())
+        ctx.cfg, ctx.first, ctx.mirror, ctx.key = cfg, first, mirror, key
+        pl = P.lookup(key)
+        if pl is not None:
+            arena = pl.arena(dev)
+            pl.run(arena, [images.data_ptr(), out.data_ptr()] + [t.data_ptr() for t in tensors])
+            ctx.plan, ctx.meta, ctx.ysel_at = pl, pl.meta, pl.ysel_at
+            ctx.save_for_backward(arena, images, *params)
+            return out
+        rec = None
+        if P.ENABLED and L._PROFILE is None and P.recording() is None:
+            rec = P.Recorder(key, dev)
+            rec.bind('images', images)
+            rec.bind('out', out)
+            for i, t in enumerate(tensors):
+                rec.bind(f't{i}', t)
+        if rec is not None:
+            with rec:
+                saved, meta, ysels, wd = _train_forward(images, first, params, buffers, padding, pool_mode, dtype,
+                                                        mirror, out)
+                if first:
+                    saved[0] = None                              # (layer 1's input is the image: an external base)
+                for i, t in enumerate(saved):
+                    if t is not None:
+                        rec.export(f's{i}', t)
+                for li in range(10):
+                    if ysels[li] is not None:
+                        rec.export(f'ysel{li}', ysels[li])
+                    if wd[li] is not None:
+                        rec.export(f'wd{li}', wd[li])
+            pl = P.lookup(key)
+            pl.meta, pl.ysel_at = meta, [li for li in range(10) if ysels[li] is not None]
+            ctx.fwd_table = pl.table                             # this pass's own addresses: for its backward's recording
+            if first:
+                saved[0] = images
+        else:
+            saved, meta, ysels, wd = _train_forward(images, first, params, buffers, padding, pool_mode, dtype, mirror,
+                                                    out)
+            ctx.fwd_table = None
+        ctx.plan = None
         ctx.ysel_at = [li for li in range(10) if ysels[li] is not None]
-        ctx.save_for_backward(*saved, *params, *[ysels[li] for li in ctx.ysel_at])
-        ctx.meta, ctx.cfg, ctx.first, ctx.mirror = meta, cfg, first, mirror
-        B, PH, PW, C = x.shape
-        return x.reshape(B, PH * PW, C).float()
+        ctx.wd_at = [li for li in range(10) if wd[li] is not None]
+        ctx.save_for_backward(*saved, *params, *[ysels[li] for li in ctx.ysel_at], *[wd[li] for li in ctx.wd_at])
+        ctx.meta = meta
+        return out
 
     @staticmethod
     def backward(ctx, dout):
         padding, pool_mode, training, dtype, _ = ctx.cfg
         if not training:
             raise L.VqaHipError('CNN backward is implemented for training-mode BatchNorm only')
-        saved, params = ctx.saved_tensors[:60], ctx.saved_tensors[60:100]
-        ysels = dict(zip(ctx.ysel_at, ctx.saved_tensors[100:]))
-        grads = [None] * 40
-        B, H, W, C = saved[55].shape
-        pool_last = ctx.meta[9][1]
-        d = dout.reshape(B, H // 2 if pool_last else H, W // 2 if pool_last else W, C).to(dtype).contiguous()
-        side = _wgrad_stream(dout.device) if WGRAD_STREAM else None
-        part = None
-        deferred = [] if DEFER_WGRAD_REDUCE else None      # weight-gradient slabs, reduced by one launch at the end
-        for li in range(9, -1, -1):
-            pad, pool, fused_in = ctx.meta[li]
-            # the block below has no pool: this block's data gradient can also do its BatchNorm-backward reduction
-            bst = None
-            if li > 0 and ctx.meta[li - 1][1] == 0 and CHANNELS[li] <= min(FUSE_BN_BWD, _ck(CHANNELS[li], dtype)):
-                bst = (saved[6 * (li - 1) + 1], coef_block(*saved[6 * (li - 1) + 2: 6 * (li - 1) + 6]))
-            elif li - 1 in ysels:       # max-pooled block below: the same sums from (d, ysel) at pooled resolution
-                bst = (ysels[li - 1], coef_block(*saved[6 * (li - 1) + 2: 6 * (li - 1) + 6]))
-            # fused_in: this layer's input x is the previous layer's raw conv output; its weight gradient re-applies
-            # that layer's BatchNorm + ReLU (saved scale / shift) as the forward conv did
-            in_coeffs = (saved[6 * (li - 1) + 2], saved[6 * (li - 1) + 3]) if fused_in else None
-            d, dw, db, dg, dbt, part = block_bwd(d, saved[6 * li: 6 * li + 6], params[4 * li], CHANNELS[li], pad, pool,
-                                                 li > 0, first=ctx.first and li == 0, wpk_d=ctx.wd[li],
-                                                 mirror=ctx.mirror and li == 0,
-                                                 params=params[4 * li: 4 * li + 4], side=side, in_coeffs=in_coeffs,
-                                                 part=part, bst=bst, defer=deferred)
-            grads[4 * li: 4 * li + 4] = [dw, db, dg, dbt]
-        if side is not None:
-            with torch.cuda.stream(side):
-                wgrad_reduce_all(deferred)
-            torch.cuda.current_stream().wait_stream(side)
+        dev = dout.device
+        dout = dout.contiguous()
+        if dout.dtype != torch.float32:
+            dout = dout.float()
+        if ctx.plan is not None:
+            arena, images = ctx.saved_tensors[:2]
+            params = ctx.saved_tensors[2:42]
         else:
-            wgrad_reduce_all(deferred)
-        return (None, None, *grads, *([None] * 20))
+            params = ctx.saved_tensors[60:100]
+            images = ctx.saved_tensors[0] if ctx.first else None
+        # where the 40 gradients go: their slots of the flat gradient buffer (optim.FlatParams; adopted by autograd as
+        # p.grad without a copy - only valid while p.grad is None), else a gradient block of this pass
+        flat = all(p.grad is None and getattr(p, '_vqa_grad_dst', None) is not None for p in params)
+        gbase = params[0]._vqa_grad_dst._base if flat else None
+        layout = getattr(gbase, '_vqa_layout_id', None) if flat else 0
+        if flat and layout is None:
+            flat, layout = False, 0
+        if flat:
+            gdsts = [p._vqa_grad_dst.view(p.shape) for p in params]
+        else:
+            offs, total = _grad_layout()
+            gbase = torch.empty(total, device=dev, dtype=torch.float32)
+            gdsts = [gbase[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
+        key = ('cnn.bwd', ctx.key, layout)
+        side = _wgrad_stream(dev) if WGRAD_STREAM else None
+        pl = P.lookup(key) if ctx.plan is not None else None
+        if pl is not None:
+            arena_b = pl.arena(dev)
+            # (bases in the order the recording bound them: fwd arena, [the image: first-layer kernels only], dout, grads)
+            pl.run(arena_b, [arena.data_ptr()] + ([images.data_ptr()] if ctx.first else []) +
+                   [dout.data_ptr(), gbase.data_ptr()], [side.cuda_stream] if side is not None else [])
+            return (None, None, *gdsts, *([None] * 30))
+        # ---- launch by launch (and recorded, when the forward pass has a plan to record against)
+        if ctx.plan is not None:
+            fp = ctx.plan
+            saved = [fp.view(arena, f's{i}') if f's{i}' in fp.exports else None for i in range(60)]
+            if ctx.first:
+                saved[0] = images
+            ysels = {li: fp.view(arena, f'ysel{li}') for li in ctx.ysel_at}
+            wd = [fp.view(arena, f'wd{li}') if f'wd{li}' in fp.exports else None for li in range(10)]
+            table = [(arena.data_ptr(), fp.arena_bytes, 0)]
+        else:
+            saved = list(ctx.saved_tensors[:60])
+            rest = ctx.saved_tensors[100:]
+            ysels = dict(zip(ctx.ysel_at, rest[:len(ctx.ysel_at)]))
+            wd = [None] * 10
+            for li, t in zip(ctx.wd_at, rest[len(ctx.ysel_at):]):
+                wd[li] = t
+            table = ctx.fwd_table
+        rec = None
+        if table is not None and P.ENABLED and L._PROFILE is None and P.recording() is None:
+            rec = P.Recorder(key, dev)
+            rec.bind_table('fwd', table)
+            if ctx.first:
+                rec.bind('images', images)
+            rec.bind('dout', dout)
+            rec.bind('grads', gbase)
+            if side is not None:
+                rec.stream('wgrad', side)
+
+        def run():
+            if not flat:
+                L.call('vqa_zero', gbase, gbase.numel() * 4)      # (the conv-bias slots are never written)
+            _train_backward(dout, saved, ysels, wd, ctx.meta, gdsts, dtype, ctx.first, ctx.mirror)
+        if rec is not None:
+            with rec:
+                run()
+        else:
+            run()
+        return (None, None, *gdsts, *([None] * 30))
 
 
 class CNN(nn.Module):
@@ -673,10 +819,7 @@ class CNN(nn.Module):
         for ci in CONV_IDX:
             conv, bn = self.convolutions[ci], self.convolutions[ci + 1]
             params += [conv.weight, conv.bias, bn.weight, bn.bias]
-            buffers += [bn.running_mean, bn.running_var]
+            buffers += [bn.running_mean, bn.running_var, bn.num_batches_tracked]
         cfg = (self.padding, 1 if self.pooling == 'max' else 2, self.training, dtype, bool(mirror))
-        out = _CnnFunction.apply(x, cfg, *params, *buffers)
-        if self.training:
-            with torch.no_grad():                  # ten counters, one launch
-                torch._foreach_add_([self.convolutions[ci + 1].num_batches_tracked for ci in CONV_IDX], 1)
-        return out
+        # (num_batches_tracked is bumped by each layer's statistics kernel, vqa_bn_finalize)
+        return _CnnFunction.apply(x, cfg, *params, *buffers)

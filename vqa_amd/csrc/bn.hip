@@ -44,8 +44,9 @@ __device__ __forceinline__ void column_sums(const float* part, int rows, int C, 
 __global__ __launch_bounds__(256) void bn_finalize(const float* part, int rows, int C, double count,
                                                    const float* gamma, const float* beta, float* running_mean,
                                                    float* running_var, float momentum, float eps, float* mean,
-                                                   float* invstd, float* scale, float* shift) {
+                                                   float* invstd, float* scale, float* shift, long* nbt) {
     const int c = blockIdx.x;
+    if (nbt && c == 0 && threadIdx.x == 0) nbt[0] += 1;        // nn.BatchNorm2d.num_batches_tracked (one writer)
     // (this kernel sits between every conv and its BatchNorm pass: the parameter loads are issued first and the rows
     // are read four at a time, so the whole kernel is two memory round trips instead of rows/256 + 2)
     float ga = 0.f, be = 0.f, rm = 0.f, rv = 0.f;
@@ -448,10 +449,10 @@ __global__ void bn_bwd_finalize(const float* part, int rows, int C, double count
 
 extern "C" int vqa_bn_finalize(void* stream, const float* part, int rows, int C, double count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                               float* mean, float* invstd, float* scale, float* shift) {
+                               float* mean, float* invstd, float* scale, float* shift, long* num_batches_tracked) {
     if (rows < 1 || C < 1) return VQA_ERR_ARG;
     hipLaunchKernelGGL(bn_finalize, dim3(C), dim3(256), 0, static_cast<hipStream_t>(stream), part, rows, C, count, gamma,
-                       beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+                       beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, num_batches_tracked);
     CHECK_LAUNCH();
     return VQA_OK;
 }

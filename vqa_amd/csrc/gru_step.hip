@@ -35,7 +35,8 @@ constexpr int KS = 8;      // K slices = waves per workgroup
 
 struct StepFwd {
     const bf16* xp;       // packed h_{t-1}, or null (t = 0: h_{-1} = 0, no product)
-    const float* hp_f;    // [B][H]  h_{t-1} (f32, for the update)
+    const float* hp_f;    // [B][H]  h_{t-1} (f32, for the update); t = 0: not read - h_{-1} = 0 is WRITTEN there
+    bf16* hp_t;           // t = 0 only: row-major h_{-1} slot of the T copy, zeroed here (the weight gradient reads it)
     const bf16* wf;       // packed W_hh
     const float* gi;      // [B][3H] input projection of step t (+ b_ih)
     const float* bhh;     // [3H]
@@ -161,7 +162,18 @@ __global__ __launch_bounds__(64 * KS) void gru_step_fwd_k(StepFwd a) {
         const float* gib = a.gi + mr * 3 * H + uj;
         load4(gib, ir); load4(gib + H, iz); load4(gib + 2 * H, in_);
         load4(a.bhh + uj, br); load4(a.bhh + H + uj, bz); load4(a.bhh + 2 * H + uj, bn);
-        load4(a.hp_f + mr * H + uj, hp);
+        if (a.xp) {
+            load4(a.hp_f + mr * H + uj, hp);
+        } else {
+            // the first time step: h_{-1} = 0.  Nobody has to zero slot 0 of h_f / h_t beforehand - this launch writes
+            // it (the backward's step 0 and the weight-gradient GEMM read it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hp[e] = 0.f;
+            if (ok) {
+                store4<float>(const_cast<float*>(a.hp_f) + (long)m * H + uj, hp);
+                store4<bf16>(a.hp_t + (long)m * H + uj, hp);
+            }
+        }
     }
     f32x4 gh[3];
     combine_slices<3>(acc, gh, wave, lane);
@@ -281,7 +293,8 @@ extern "C" int vqa_gru_fwd_fused(void* stream, const float* gi, const void* wf, 
     const long bh = (long)B * H, ph = packed_elems(B, H);
     const dim3 grid((unsigned)((H / 16) * ((B + 63) / 64)));
     for (int t = 0; t < T; ++t) {
-        StepFwd a{t == 0 ? nullptr : static_cast<const bf16*>(h_p) + t * ph, h_f + t * bh, static_cast<const bf16*>(wf),
+        StepFwd a{t == 0 ? nullptr : static_cast<const bf16*>(h_p) + t * ph, h_f + t * bh,
+                  t == 0 ? static_cast<bf16*>(h_t) : nullptr, static_cast<const bf16*>(wf),
                   gi + (long)t * B * 3 * H, b_hh, h_f + (t + 1) * bh, static_cast<bf16*>(h_t) + (t + 1) * bh,
                   static_cast<bf16*>(h_p) + (t + 1) * ph, save + (long)t * B * 4 * H, B, H};
         hipLaunchKernelGGL(gru_step_fwd_k, grid, dim3(64 * KS), 0, s, a);

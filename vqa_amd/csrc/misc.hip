@@ -233,6 +233,40 @@ __global__ void cast_pad(const TS* __restrict__ src, int M, int N, int lds, TD* 
     }
 }
 
+// dst[n][m] = src[m][n] in the destination dtype, columns m in [M, ldd) zero: the transposed, cast copy of an f32 master
+// weight (the GRU's W_ih^T for its input gradient) through a 32 x 33 LDS tile - both sides move whole row segments.
+template <typename TD>
+__global__ __launch_bounds__(256) void cast_transpose(const float* __restrict__ src, int M, int N, int lds,
+                                                      TD* __restrict__ dst, int ldd) {
+    __shared__ float tile[32][33];
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int m = m0 + r, n = n0 + tx;
+        tile[r][tx] = (m < M && n < N) ? src[(long)m * lds + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, m = m0 + tx;
+        if (n < N && m < ldd) dst[(long)n * ldd + m] = from_f32<TD>(tile[tx][r]);
+    }
+}
+
+// nbytes (a multiple of 4) of zeros from a 4-byte aligned address: the step's own fill (embedding gradient, unwritten
+// gradient slots) - 16-byte stores from the first 16-byte boundary on
+__global__ void zero_fill(unsigned* __restrict__ p, long nwords) {
+    const long head = (4 - ((reinterpret_cast<uintptr_t>(p) >> 2) & 3)) & 3;       // words before the boundary
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long h = head < nwords ? head : nwords;
+    if (i < h) p[i] = 0u;
+    const long nvec = (nwords - h) / 4;
+    uint4* v = reinterpret_cast<uint4*>(p + h);
+    for (long k = i; k < nvec; k += (long)gridDim.x * blockDim.x) v[k] = make_uint4(0u, 0u, 0u, 0u);
+    const long tail0 = h + nvec * 4;
+    if (i < nwords - tail0) p[tail0 + i] = 0u;
+}
+
 // ---------------------------------------------------------------------------------------- embedding
 // X[t][b][0..ldx) = emb[q[b][t]][0..E), zero padded   (time-major so every GRU step reads a contiguous slab)
 // A token id outside [0, V) (nn.Embedding raises on it) reads nothing: its row is filled with NaN, which reaches the
@@ -790,6 +824,27 @@ extern "C" int vqa_cast_pad(void* stream, int src_dtype, int dst_dtype, const vo
     else if (src_dtype == VQA_BF16 && dst_dtype == VQA_F32) GO(bf16, float);
     else return VQA_ERR_ARG;
 #undef GO
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_cast_transpose(void* stream, int dst_dtype, const float* src, int M, int N, int lds, void* dst,
+                                  int ldd) {
+    if (!src || !dst || M < 1 || N < 1 || lds < N || ldd < M) return VQA_ERR_ARG;
+    const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((ldd + 31) / 32));
+    BY_T(dst_dtype, hipLaunchKernelGGL(cast_transpose<bf16>, grid, dim3(256), 0, ST, src, M, N, lds, (bf16*)dst, ldd),
+         hipLaunchKernelGGL(cast_transpose<float>, grid, dim3(256), 0, ST, src, M, N, lds, (float*)dst, ldd));
+    CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_zero(void* stream, void* p, long nbytes) {
+    if (!p || nbytes < 0 || (nbytes & 3) || (reinterpret_cast<uintptr_t>(p) & 3)) return VQA_ERR_ARG;
+    if (nbytes == 0) return VQA_OK;
+    const long nwords = nbytes / 4, nvec = nwords / 4 + 8;
+    long blocks = (nvec + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_fill, dim3((unsigned)blocks), dim3(256), 0, ST, static_cast<unsigned*>(p), nwords);
     CHECK_LAUNCH();
     return VQA_OK;
 }

@@ -82,11 +82,14 @@ def _recurrence_fwd(x, E, dtype, w_ih, w_hh, b_ih, b_hh, B, T, allow_persistent=
     H, dev = w_hh.shape[1], x.device
     wih = ops.cast_pad(w_ih, dtype, ops.pad8(E))             # [3H, E] (row stride padded to 8)
     gi = ops.gemm(x[:, :E], wih, bias=b_ih)                  # [T*B, 3H] fp32
-    h_f = torch.zeros(T + 1, B, H, device=dev, dtype=torch.float32)   # h_{-1} = 0, h_0 .. h_{T-1}
-    h_t = torch.zeros(T + 1, B, H, device=dev, dtype=dtype)
     save = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
     persistent = allow_persistent and _persistent_ok(dtype, H)
-    if not persistent and _fused_ok(dtype, H):
+    fused = not persistent and _fused_ok(dtype, H)
+    # slot 0 = h_{-1} = 0: the fused step kernels write it themselves in their first launch; the other forms read it
+    mk = torch.empty if fused else torch.zeros
+    h_f = mk(T + 1, B, H, device=dev, dtype=torch.float32)            # h_{-1}, h_0 .. h_{T-1}
+    h_t = mk(T + 1, B, H, device=dev, dtype=dtype)
+    if fused:
         # one launch per time step: the recurrent GEMM with the gates in its epilogue, operands in MFMA-fragment order
         # (csrc/gru_step.hip); W_hh is packed straight from the f32 master
         wf = torch.empty(3 * H * H, device=dev, dtype=dtype)
@@ -111,7 +114,7 @@ def _recurrence_bwd(x, E, dtype, h_f, h_t, save, w_ih, w_hh, b_ih, b_hh, dh_last
     """BPTT of one layer.  dh_last [B,H] / dh_seq [T,B,H] (either may be None): gradients w.r.t. the last / every
     step's output.  Returns (dx [T*B,E] f32, dw_ih, dw_hh, db_ih, db_hh)."""
     H, dev = w_hh.shape[1], x.device
-    wih_T = ops.cast_pad(w_ih.t().contiguous(), dtype)       # [E, 3H]
+    wih_T = ops.cast_transpose(w_ih, dtype)                  # [E, 3H]: W_ih^T in the MFMA dtype, one launch
     dgi = torch.empty(T * B, 3 * H, device=dev, dtype=dtype)
     dgh = torch.empty(T * B, 3 * H, device=dev, dtype=dtype)
     if dh_seq is not None:
@@ -165,7 +168,7 @@ class _GruFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         hseq_t = h_t[1:].reshape(T * B, H)
         ctx.mark_non_differentiable(hseq_t)
-        return h_f[T].clone(), h_f[1:], hseq_t
+        return h_f[T], h_f[1:], hseq_t
 
     @staticmethod
     def backward(ctx, dh_last, dh_seq, _dt=None):
@@ -175,7 +178,9 @@ class _GruFunction(torch.autograd.Function):
         dx, dw_ih, dw_hh, db_ih, db_hh = _recurrence_bwd(x, E, ctx.dtype, h_f, h_t, save, w_ih, w_hh, b_ih, b_hh,
                                                          dh_last, dh_seq, B, T)
         demb = ops.grad_dst(emb)
-        demb = torch.zeros_like(emb) if demb is None else demb.zero_()
+        if demb is None:
+            demb = torch.empty_like(emb)
+        L.call('vqa_zero', demb, demb.numel() * 4)            # (the scatter below writes only the rows that occur)
         ws = torch.empty(L.lib().vqa_embed_bwd_ws_bytes(B, T, E), device=q.device, dtype=torch.uint8)
         L.call('vqa_embed_bwd', q, dx, B, T, E, emb.shape[0], dx.stride(0), demb, ws)
         return None, None, demb, dw_ih, dw_hh, db_ih, db_hh
@@ -196,7 +201,7 @@ class _GruStackedFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         hseq_t = h_t[1:].reshape(T * B, H)
         ctx.mark_non_differentiable(hseq_t)
-        return h_f[T].clone(), h_f[1:], hseq_t
+        return h_f[T], h_f[1:], hseq_t
 
     @staticmethod
     def backward(ctx, dh_last, dh_seq, _dt=None):

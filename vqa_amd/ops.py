@@ -164,6 +164,15 @@ def cast_pad(src, dtype, ldd=None, scale=None):
     return dst[:, :N]
 
 
+def cast_transpose(src, dtype):
+    """f32 [M,N] -> its transpose [N,M] in `dtype` (row stride padded to 8, pad columns zero); returns the [N,M] view."""
+    M, N = src.shape
+    assert src.dtype == torch.float32 and src.stride(1) == 1
+    dst = torch.empty(N, pad8(M), device=src.device, dtype=dtype)
+    L.call('vqa_cast_transpose', L.dt(dst), src, M, N, src.stride(0), dst, dst.stride(0))
+    return dst[:, :M]
+
+
 def fc_bce(x, W, target):
     """The classifier GEMM with the loss in its epilogue (reference vqa_model.py:103 + :215): x [B,H] and W [C,H] in the
     MFMA dtype, target dense fp32 [B,C] or the sparse pair (labels, scores) -> (logits fp32 [B,C], loss [1],

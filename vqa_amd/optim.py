@@ -26,6 +26,9 @@ def _bucket_of(name):
     return 0
 
 
+_layout_ids = iter(range(1, 1 << 62))
+
+
 class FlatParams:
     def __init__(self, module):
         named = sorted(module.named_parameters(), key=lambda kv: _bucket_of(kv[0]))   # stable: head, gru, cnn
@@ -35,6 +38,9 @@ class FlatParams:
         n = sum(pad(p.numel()) for _, p in named)
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)     # the gaps stay zero in all four buffers
         self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        # (recorded plans bake a gradient's offset inside this buffer into their pointer arguments: cnn.py keys them by
+        # this id, so another buffer - another layout - records plans of its own)
+        self.grad._vqa_layout_id = next(_layout_ids)
         self.names, self.params, self.bucket_ranges = [], [], []
         off, cur, start = 0, None, 0
         for name, p in named:

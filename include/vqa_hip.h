@@ -310,10 +310,11 @@ int vqa_clip_adamax(void* stream, float* p, const float* g, float* m, float* u, 
  * 3 pointer as (base index << 48 | byte offset), 4 NULL, 5 / 6 host array of n pointers / ints (n inline words follow).
  * bases = this call's base addresses (scratch arena, inputs, parameters, gradient buffer ...), streams = hipStream_t
  * handles (index 0 = the caller's current stream).  Stateless: nothing is kept between calls, no allocation; an
- * ordering point creates, records, waits for and destroys one event.  Returns 0, or the failing op's status |
+ * ordering point records and waits for the caller's k-th event, or - events == NULL - creates, uses and destroys one.  Returns 0, or the failing op's status |
  * (1-based op index << 8); a malformed plan is status 1. */
 int vqa_plan_opcode(const char* name);
-int vqa_run_plan(const long* words, long n_words, void* const* bases, int n_bases, void* const* streams, int n_streams);
+int vqa_run_plan(const long* words, long n_words, void* const* bases, int n_bases, void* const* streams, int n_streams,
+                 void* const* events /* NULL, or one hipEvent_t per ordering point, in order */, int n_events);
 
 /* ---------------------------------------------------------------- hardware-layout probe (tests only) */
 int vqa_probe_tr16(void* stream, const void* in, float* out);

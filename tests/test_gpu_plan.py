@@ -105,21 +105,21 @@ def test_run_plan_refuses_malformed_plans():
     bases = (ctypes.c_void_p * 1)(0)
     streams = (ctypes.c_void_p * 1)(L._raw_stream())
     bad_magic = (ctypes.c_long * 2)(123, 0)
-    assert lib.vqa_run_plan(bad_magic, 2, bases, 1, streams, 1) == 1
+    assert lib.vqa_run_plan(bad_magic, 2, bases, 1, streams, 1, None, 0) == 1
     empty = (ctypes.c_long * 2)(P.MAGIC, 0)
-    assert lib.vqa_run_plan(empty, 2, bases, 1, streams, 1) == 0
+    assert lib.vqa_run_plan(empty, 2, bases, 1, streams, 1, None, 0) == 0
     truncated = (ctypes.c_long * 3)(P.MAGIC, 1, 0)
-    assert lib.vqa_run_plan(truncated, 3, bases, 1, streams, 1) == 1
+    assert lib.vqa_run_plan(truncated, 3, bases, 1, streams, 1, None, 0) == 1
     # an op whose pointer names a base the call does not pass: refused before anything is launched (op 1)
     op = lib.vqa_plan_opcode(b'vqa_zero')
     words = [P.MAGIC, 1, op, 0, 2, P.K_PTR, (5 << 48) | 0, P.K_INT, 16]
     arr = (ctypes.c_long * len(words))(*words)
-    assert lib.vqa_run_plan(arr, len(words), bases, 1, streams, 1) == (1 | (1 << 8))
+    assert lib.vqa_run_plan(arr, len(words), bases, 1, streams, 1, None, 0) == (1 | (1 << 8))
     # a well-formed one-op plan: zero 64 bytes at offset 32 of base 0
     x = torch.ones(64, device='cuda')
     bases[0] = x.data_ptr()
     words = [P.MAGIC, 1, op, 0, 2, P.K_PTR, 32, P.K_INT, 64]
     arr = (ctypes.c_long * len(words))(*words)
-    assert lib.vqa_run_plan(arr, len(words), bases, 1, streams, 1) == 0
+    assert lib.vqa_run_plan(arr, len(words), bases, 1, streams, 1, None, 0) == 0
     torch.cuda.synchronize()
     assert x[:8].eq(1).all() and x[8:24].eq(0).all() and x[24:].eq(1).all()

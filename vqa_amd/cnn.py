@@ -331,7 +331,7 @@ def coef_block(scale, shift, mean, invstd):
 
 
 def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, gdst, first=False, wpk_d=None, mirror=False,
-              side=None, in_coeffs=None, part=None, bst=None, defer=None):
+              side=None, in_coeffs=None, part=None, bst=None, defer=None, hold=None):
     """d = gradient w.r.t. the block output (NHWC, activation dtype).  gdst = (dw, dgamma, dbeta): where the layer's
     parameter gradients are written (slots of the flat gradient buffer, or of the pass's own gradient block; the conv
     bias feeds a training-mode BatchNorm, so its gradient is identically zero - the reference produces rounding noise
@@ -339,7 +339,9 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, gdst, first=False, wpk_
     Returns (dx, below).
     side: HIP stream for the weight gradient (off the dgrad -> BatchNorm-backward chain), None = current stream.
     part: this block's BatchNorm-backward partial sums, already produced by the data gradient of the block above.
-    bst = (y, coef) of the block BELOW: this block's data gradient also produces that block's partial sums (`below`)."""
+    bst = (y, coef) of the block BELOW: this block's data gradient also produces that block's partial sums (`below`).
+    hold (a list, side stream only): the weight gradient is not issued here - a closure that orders the side stream
+    behind the main stream AT THE TIME IT IS CALLED and then issues it is appended instead (see WGRAD_HOLD)."""
     x, y, scale, shift, mean, invstd = saved
     dev = y.device
     B, H, W, C = y.shape
@@ -423,6 +425,15 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, gdst, first=False, wpk_
 
     if side is None:
         wgrad()
+        dx, below = dgrad()
+    elif hold is not None:
+        def later():
+            P.stream_wait(side, torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                wgrad()
+        hold.append(later)
+        dy.record_stream(side)
+        x.record_stream(side)
         dx, below = dgrad()
     else:
         # (enqueueing the data gradient first instead measured the same)
@@ -512,6 +523,11 @@ WGRAD_RESERVE = int(os.environ.get('VQA_WGRAD_RESERVE', '0'))
 # and those two run beside it: 4.180 -> 4.120 ms/step (5 alternations of 60 steps).  VQA_FIRST_WGRAD_MAIN=0: as before.
 FIRST_WGRAD_MAIN = os.environ.get('VQA_FIRST_WGRAD_MAIN', '1') != '0'
 FIRST_RESERVE = int(os.environ.get('VQA_FIRST_RESERVE', '0'))
+# The deep layers' weight gradients (MFMA-bound, like the deep data gradients that run at the same time) are held back
+# and released onto the weight-gradient stream when the backward's main chain reaches the HBM-bound shallow blocks:
+# layers >= WGRAD_HOLD_FROM are issued after the main-stream launches of layer WGRAD_RELEASE_AT (0 / -1 = no holding).
+WGRAD_HOLD_FROM = int(os.environ.get('VQA_WGRAD_HOLD_FROM', '0'))
+WGRAD_RELEASE_AT = int(os.environ.get('VQA_WGRAD_RELEASE_AT', '3'))
 
 
 def _bwd_slices(B, nbytes):
@@ -541,7 +557,7 @@ def _wgrad_stream(dev):
 def _knobs():
     """Everything in this module the recorded launch sequence depends on (part of every plan key)."""
     return (WGRAD_STREAM, FUSE_BN_FWD, FUSE_BN_BWD, FUSE_FIRST_BN, FUSE_POOL_BWD, DEFER_WGRAD_REDUCE, BWD_SLICES,
-            BWD_SLICE_MIN_MB, WGRAD_RESERVE, FIRST_WGRAD_MAIN, FIRST_RESERVE)
+            BWD_SLICE_MIN_MB, WGRAD_RESERVE, FIRST_WGRAD_MAIN, FIRST_RESERVE, WGRAD_HOLD_FROM, WGRAD_RELEASE_AT)
 
 
 def out_regions(size, padding):
@@ -618,6 +634,7 @@ def _train_backward(dout, saved, ysels, wd, meta, gdsts, dtype, first, mirror):
     side = _wgrad_stream(dout.device) if WGRAD_STREAM else None
     part = None
     deferred = [] if DEFER_WGRAD_REDUCE else None      # weight-gradient slabs, reduced by one launch at the end
+    held = []
     for li in range(9, -1, -1):
         pad, pool, fused_in = meta[li]
         # the block below has no pool: this block's data gradient can also do its BatchNorm-backward reduction
@@ -632,7 +649,14 @@ def _train_backward(dout, saved, ysels, wd, meta, gdsts, dtype, first, mirror):
         g = gdsts[4 * li: 4 * li + 4]
         d, part = block_bwd(d, saved[6 * li: 6 * li + 6], None, CHANNELS[li], pad, pool, li > 0, (g[0], g[2], g[3]),
                             first=first and li == 0, wpk_d=wd[li], mirror=mirror and li == 0, side=side,
-                            in_coeffs=in_coeffs, part=part, bst=bst, defer=deferred)
+                            in_coeffs=in_coeffs, part=part, bst=bst, defer=deferred,
+                            hold=held if (side is not None and 0 < WGRAD_HOLD_FROM <= li) else None)
+        if held and li <= WGRAD_RELEASE_AT:
+            for fn in held:
+                fn()
+            held = []
+    for fn in held:
+        fn()
     if side is not None:
         with torch.cuda.stream(side):
             wgrad_reduce_all(deferred)
@@ -666,7 +690,7 @@ class _CnnFunction(torch.autograd.Function):
         B, _, IH, IW = images.shape
         ko = out_regions(IH, padding) * out_regions(IW, padding)
         out = torch.empty(B, ko, 256, device=dev, dtype=torch.float32)
-        key = ('cnn.fwd', tuple(images.shape), images.dtype, padding, pool_mode, dtype, mirror, first, _knobs())
+        key = ('cnn.fwd', dev.index, tuple(images.shape), images.dtype, padding, pool_mode, dtype, mirror, first, _knobs())
         ctx.cfg, ctx.first, ctx.mirror, ctx.key = cfg, first, mirror, key
         pl = P.lookup(key)
         if pl is not None:

@@ -52,12 +52,13 @@ extern "C" int vqa_plan_opcode(const char* name) {
 
 // status 0, or (status of the failing op) | (its 1-based index << 8); a malformed plan is status 1 with index 0
 extern "C" int vqa_run_plan(const long* words, long n_words, void* const* bases, int n_bases, void* const* streams,
-                            int n_streams) {
+                            int n_streams, void* const* events, int n_events) {
     if (!words || n_words < 2 || words[0] != PLAN_MAGIC || !bases || !streams || n_streams < 1) return 1;
     const long n_ops = words[1];
     long w = 2;
     void* parr[MAX_PTRS];
     int iarr[MAX_INTS];
+    int next_event = 0;
     for (long op = 0; op < n_ops; ++op) {
         if (w + 3 > n_words) return 1;
         const long entry = words[w], sidx = words[w + 1], nslots = words[w + 2];
@@ -96,7 +97,12 @@ extern "C" int vqa_run_plan(const long* words, long n_words, void* const* bases,
             if (nslots != 1 || slot[0].i < 0 || slot[0].i >= n_streams) return 1;
             hipEvent_t ev;
             status = 2;
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+            if (events && next_event < n_events) {
+                // the caller's own events (hipEvent_t handles, one per ordering point, reusable call after call)
+                ev = static_cast<hipEvent_t>(events[next_event++]);
+                status = (hipEventRecord(ev, static_cast<hipStream_t>(streams[slot[0].i])) == hipSuccess &&
+                          hipStreamWaitEvent(static_cast<hipStream_t>(streams[sidx]), ev, 0) == hipSuccess) ? 0 : 2;
+            } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
                 const bool good = hipEventRecord(ev, static_cast<hipStream_t>(streams[slot[0].i])) == hipSuccess &&
                                   hipStreamWaitEvent(static_cast<hipStream_t>(streams[sidx]), ev, 0) == hipSuccess;
                 (void)hipEventDestroy(ev);            // (released by the runtime once the recorded work has completed)

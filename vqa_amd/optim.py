@@ -200,6 +200,12 @@ class FlatAdamax:
 STEP_PRIORITY = os.environ.get('VQA_STEP_PRIORITY', '1') != '0'
 # the loss formed in the classifier GEMM's epilogue (VQA.forward_loss) instead of a criterion pass over the logits
 FUSED_LOSS = os.environ.get('VQA_FUSED_LOSS', '1') != '0'
+# The host may run at most this many steps ahead of the GPU (0 = unbounded): before it issues step n it waits for step
+# n - MAX_AHEAD to have finished.  With the encoder passes issued by one call each the host needs 2.5 ms per 4.1 ms step
+# and, unbounded, ends up tens of steps ahead - and the GPU gets SLOWER for it (same-box A/B, 3 alternations of 60
+# steps: unbounded 4.16 ms/step, at most 4 ahead 4.10, at most 2 ahead 4.09, at most 1 ahead 4.33 - the host then
+# cannot hide its own issue time).
+MAX_AHEAD = int(os.environ.get('VQA_MAX_AHEAD', '2'))
 _STEP_STREAMS = {}
 
 
@@ -216,6 +222,7 @@ class Trainer:
             model._dp_fold_streams = True           # (a plain bool: the module still pickles whole)
         self.opt = FlatAdamax(self.flat, lr=lr, max_norm=max_norm)
         self.criterion = SoftScoreBCELoss()
+        self._marks, self._mark_i = [], 0           # one event per step in flight (a ring of MAX_AHEAD)
 
     def step(self, images, questions, target, flip=True, dropout_noise=None):
         """The step runs on a high-priority HIP stream of its own, ordered after and before the caller's current
@@ -245,7 +252,22 @@ class Trainer:
             _STEP_STREAMS[key] = torch.cuda.Stream(dev, priority=-1)
         return _STEP_STREAMS[key]
 
+    def _throttle(self):
+        """Before issuing a step: wait (on the host) for the step MAX_AHEAD steps back."""
+        if MAX_AHEAD > 0 and len(self._marks) >= MAX_AHEAD:
+            self._marks[(self._mark_i + 1) % len(self._marks)].synchronize()     # the oldest mark of the ring
+
+    def _mark(self):
+        if MAX_AHEAD > 0:
+            if len(self._marks) < MAX_AHEAD:
+                self._marks.append(torch.cuda.Event())
+                self._mark_i = len(self._marks) - 1
+            else:
+                self._mark_i = (self._mark_i + 1) % len(self._marks)
+            self._marks[self._mark_i].record()
+
     def _step(self, images, questions, target, flip=True, dropout_noise=None):
+        self._throttle()
         self.opt.zero_grad()
         # the reference flips the batch tensor (vqa_model.py:250); same coin, but the first conv reads it mirrored
         mirror = flip and self.model.flip.draw()
@@ -263,4 +285,5 @@ class Trainer:
             self.flat.collect()
         self.buckets.wait()
         self.opt.step()
+        self._mark()
         return loss.detach()

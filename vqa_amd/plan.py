@@ -23,6 +23,8 @@ from . import _lib as L
 
 # VQA_PLAN=0: always the per-launch path
 ENABLED = os.environ.get('VQA_PLAN', '1') != '0'
+# VQA_PLAN_EVENTS=0: an ordering point creates and destroys its event inside vqa_run_plan instead of reusing one of ours
+OWN_EVENTS = os.environ.get('VQA_PLAN_EVENTS', '1') != '0'
 MAGIC = 0x56514150314c
 K_INT, K_F32, K_F64, K_PTR, K_NULL, K_PTRARR, K_INTARR = range(7)
 OP_SYNC = -1
@@ -49,28 +51,33 @@ class PlanError(L.VqaHipError):
 
 
 class Recorder:
-    """with Recorder(key, device) as rec: ... the ordinary path, using empty() / stream_wait() / _lib.call ..."""
+    """with Recorder(key, device) as rec: ... the ordinary path, using empty() / stream_wait() / _lib.call ...
+
+    Arena layout.  Offsets are assigned when the recording ends, from the temporaries' LIFETIMES in the recorded op
+    sequence: a temporary's bytes are handed out again once its last op is behind - as torch's caching allocator
+    recycles the blocks of the per-launch path - instead of every temporary getting bytes of its own.  That is not
+    about the footprint (288 GB): a dead tensor whose lines still sit in the 256 MB Infinity Cache is overwritten
+    there and never travels to HBM, while a layout without reuse writes every dead byte back (same-box A/B of the whole
+    step: 4.29 ms with one offset per temporary against 4.245 per-launch).  A temporary that a side stream touches
+    stays reserved until the main stream has waited for that stream (the ordering point after its last use); an
+    exported one (saved for the backward) is never recycled."""
 
     def __init__(self, key, device):
         self.key, self.device = key, device
-        self.words, self.n_ops = [], 0
-        self.size = 0
-        self.tables = []            # per base: list of (ptr, nbytes, byte offset inside the base)
+        self.ops = []               # ('call', entry, stream idx, [encoded args]) | ('sync', waiter idx, signal idx)
+        self.allocs = []            # [ptr, nbytes, first op, last op, {stream: its first op}, exported]
+        self.tables = [None]        # per external base: list of (ptr, nbytes, byte offset inside the base); [0] = arena
         self.names = ['arena']      # base names, index = base index
-        self.tables.append([])
         self.keep = []              # recorded temporaries stay alive until the end: no address is handed out twice
         self.streams = {L._raw_stream(): 0}
         self.stream_names = ['main']
-        self.exports = {}
-        self.live = []              # (ptr, nbytes, arena offset) of the exported tensors: what outlives the recording
+        self.exports = {}           # name -> (alloc id, delta, shape, dtype)
         self.ok = True
 
     # ---- bases
     def alloc(self, shape, dtype):
         t = torch.empty(shape, device=self.device, dtype=dtype)
-        nbytes = t.numel() * t.element_size()
-        self.tables[0].append((t.data_ptr(), nbytes, self.size))
-        self.size += -(-max(nbytes, 1) // ALIGN) * ALIGN
+        self.allocs.append([t.data_ptr(), t.numel() * t.element_size(), len(self.ops), len(self.ops), {}, False])
         self.keep.append(t)
         return t
 
@@ -81,7 +88,7 @@ class Recorder:
         self.keep.append(tensor)
 
     def bind_table(self, name, table):
-        """An external base made of several recorded ranges: the allocations of another pass's arena."""
+        """An external base made of several recorded ranges: the exported tensors of another pass's arena."""
         self.names.append(name)
         self.tables.append(list(table))
 
@@ -91,26 +98,28 @@ class Recorder:
 
     def export(self, name, t):
         """Remember where a tensor of this pass lives in the arena, so that a replay can hand out a view of it."""
-        b, off = self._ref(t.data_ptr())
-        if b != 0:
+        ref = self._ref(t.data_ptr(), None)
+        if ref[0] != 'a':
             raise PlanError(f'export {name}: not an arena tensor')
-        self.exports[name] = (off, tuple(t.shape), t.dtype)
-        self.live.append((t.data_ptr(), t.numel() * t.element_size(), off))
+        self.allocs[ref[1]][5] = True
+        self.exports[name] = (ref[1], ref[2], tuple(t.shape), t.dtype, t.data_ptr(), t.numel() * t.element_size())
 
-    def _ref(self, ptr):
-        # the LATEST matching range wins inside a table (none is ever reused while recording, see keep)
-        for b in range(len(self.tables)):
+    def _ref(self, ptr, sidx):
+        """-> ('a', alloc id, delta) for an arena temporary (its use by stream `sidx` at the current op is noted), or
+        ('b', base index, byte offset) for an external base."""
+        for i in range(len(self.allocs) - 1, -1, -1):
+            a = self.allocs[i]
+            if a[0] <= ptr < a[0] + max(a[1], 1):
+                if sidx is not None:
+                    a[3] = len(self.ops)
+                    a[4].setdefault(sidx, len(self.ops))
+                return ('a', i, ptr - a[0])
+        for b in range(1, len(self.tables)):
             for p0, n, off in reversed(self.tables[b]):
                 if p0 <= ptr < p0 + max(n, 1):
-                    return b, off + (ptr - p0)
+                    return ('b', b, off + (ptr - p0))
         raise PlanError(f'plan {self.key[0]}: a pointer argument belongs to no base (allocate it with plan.empty or '
                         f'bind it)')
-
-    def _pref(self, t):
-        if t is None:
-            return -1
-        b, off = self._ref(t.data_ptr())
-        return (b << 48) | off
 
     # ---- ops
     def op(self, name, raw_stream, args):
@@ -121,29 +130,130 @@ class Recorder:
         if entry < 0:
             raise PlanError(f'{name} has no plan thunk (scripts/gen_plan_thunks.py)')
         argtypes = L.declared_prototypes()[name][1][1:]
-        w = [entry, sidx, len(args)]
+        pref = lambda t: None if t is None else self._ref(t.data_ptr(), sidx)
+        enc = []
         for a, ct in zip(args, argtypes):
             if isinstance(a, torch.Tensor):
-                w += [K_PTR, self._pref(a)]
+                enc.append((K_PTR, pref(a)))
             elif a is None:
-                w += [K_NULL, 0]
+                enc.append((K_NULL, 0))
             elif isinstance(a, (list, tuple)):
                 if all(isinstance(v, int) and not isinstance(v, bool) for v in a) and a:
-                    w += [K_INTARR, len(a)] + [int(v) for v in a]
+                    enc.append((K_INTARR, [int(v) for v in a]))
                 else:
-                    w += [K_PTRARR, len(a)] + [self._pref(v) for v in a]
+                    enc.append((K_PTRARR, [pref(v) for v in a]))
             elif ct is ctypes.c_float:
-                w += [K_F32, int.from_bytes(bytes(ctypes.c_float(a)), 'little')]
+                enc.append((K_F32, int.from_bytes(bytes(ctypes.c_float(a)), 'little')))
             elif ct is ctypes.c_double:
-                w += [K_F64, int.from_bytes(bytes(ctypes.c_double(a)), 'little', signed=True)]
+                enc.append((K_F64, int.from_bytes(bytes(ctypes.c_double(a)), 'little', signed=True)))
             else:
-                w += [K_INT, int(a)]
-        self.words += w
-        self.n_ops += 1
+                enc.append((K_INT, int(a)))
+        self.ops.append(('call', entry, sidx, enc))
 
     def sync(self, waiter_raw, signal_raw):
-        self.words += [OP_SYNC, self.streams[waiter_raw], 1, K_INT, self.streams[signal_raw]]
-        self.n_ops += 1
+        self.ops.append(('sync', self.streams[waiter_raw], self.streams[signal_raw]))
+
+    # ---- layout + encoding
+    def _layout(self):
+        """Byte offset of every temporary (see the class comment) -> (offsets, arena size)."""
+        n_ops = len(self.ops)
+        # the op after which stream s's work so far is known to the main stream: the next "main waits for s"
+        joins = {}
+        for i, o in enumerate(self.ops):
+            if o[0] == 'sync' and o[1] == 0:
+                joins.setdefault(o[2], []).append(i)
+        release = []
+        for ptr, nbytes, first, last, streams, exported in self.allocs:
+            r = last
+            if exported:
+                r = n_ops + 1
+            else:
+                for s in streams:               # (stream indices that touched it)
+                    if s != 0:
+                        later = [j for j in joins.get(s, ()) if j >= last]
+                        r = max(r, later[0] if later else n_ops + 1)
+            release.append(r)
+        # "stream s waits for the main stream" ordering points: a temporary first touched on s may only take over bytes
+        # whose previous owner was done (in main-stream order) before the last such point ahead of that first touch
+        forks = {}
+        for i, o in enumerate(self.ops):
+            if o[0] == 'sync' and o[2] == 0:
+                forks.setdefault(o[1], []).append(i)
+        free, top, offsets = [], 0, [0] * len(self.allocs)        # free: sorted list of [offset, size, release op]
+        live = []                                                  # (release op, offset, size)
+        for i, (ptr, nbytes, first, last, streams, exported) in enumerate(self.allocs):
+            # blocks whose last use lies before this temporary's creation return to the free list
+            still = []
+            for r, off, size in live:
+                if r < first:
+                    free.append([off, size, r])
+                else:
+                    still.append((r, off, size))
+            live = still
+            free.sort()
+            merged = []
+            for off, size, r in free:
+                if merged and merged[-1][0] + merged[-1][1] == off:
+                    merged[-1][1] += size
+                    merged[-1][2] = max(merged[-1][2], r)
+                else:
+                    merged.append([off, size, r])
+            free = merged
+            bound = first
+            for s_, f_ in streams.items():
+                if s_ != 0:
+                    before = [j for j in forks.get(s_, ()) if j <= f_]
+                    bound = min(bound, before[-1] if before else -1)
+            gran = (2 << 20) if nbytes >= (1 << 20) else 512       # torch's allocator: 2 MiB / 512 B granules
+            size = -(-max(nbytes, 1) // gran) * gran
+            best = None
+            for k, (off, fsize, r) in enumerate(free):
+                aoff = -(-off // gran) * gran
+                if r < bound and aoff + size <= off + fsize and (best is None or fsize < free[best][1]):
+                    best = k
+            if best is None:
+                aoff = -(-top // gran) * gran
+                if aoff > top:
+                    free.append([top, aoff - top, -1])
+                top = aoff + size
+            else:
+                off, fsize, r = free.pop(best)
+                aoff = -(-off // gran) * gran
+                if aoff > off:
+                    free.append([off, aoff - off, r])
+                if aoff + size < off + fsize:
+                    free.append([aoff + size, off + fsize - aoff - size, r])
+            offsets[i] = aoff
+            live.append((release[i], aoff, size))
+        return offsets, max(top, ALIGN)
+
+    def encode(self):
+        offsets, size = self._layout()
+
+        def word(ref):
+            if ref is None:
+                return -1
+            kind, b, delta = ref
+            return (0 << 48) | (offsets[b] + delta) if kind == 'a' else (b << 48) | delta
+        words = []
+        for o in self.ops:
+            if o[0] == 'sync':
+                words += [OP_SYNC, o[1], 1, K_INT, o[2]]
+                continue
+            _, entry, sidx, enc = o
+            words += [entry, sidx, len(enc)]
+            for kind, val in enc:
+                if kind == K_PTR:
+                    words += [K_PTR, word(val)]
+                elif kind == K_PTRARR:
+                    words += [K_PTRARR, len(val)] + [word(v) for v in val]
+                elif kind == K_INTARR:
+                    words += [K_INTARR, len(val)] + val
+                else:
+                    words += [kind, val]
+        exports = {name: (offsets[a] + delta, shape, dtype) for name, (a, delta, shape, dtype, _, _) in self.exports.items()}
+        live = [(ptr, nbytes, offsets[a] + delta) for (a, delta, _, _, ptr, nbytes) in self.exports.values()]
+        return words, size, exports, live
 
     # ---- context
     def __enter__(self):
@@ -166,18 +276,21 @@ class Recorder:
 
 class Plan:
     def __init__(self, rec):
-        words = [MAGIC, rec.n_ops] + rec.words
+        body, size, exports, live = rec.encode()
+        words = [MAGIC, len(rec.ops)] + body
         self.n_words = len(words)
         self.words = (ctypes.c_long * self.n_words)(*words)
-        self.arena_bytes = max(rec.size, ALIGN)
+        self.arena_bytes = size
         self.names = list(rec.names)
         self.stream_names = list(rec.stream_names)
-        self.exports = dict(rec.exports)
+        self.exports = exports
         # the recorded pass's own addresses of what it exported: a later pass (its backward) records against them.  Only
         # the exported tensors - the other temporaries are freed when the recording ends, and their addresses may be
         # handed out again (to the backward's incoming gradient, say)
-        self.table = list(rec.live)
-        self.n_ops = rec.n_ops
+        self.table = live
+        self.n_ops = len(rec.ops)
+        self.n_syncs = sum(1 for o in rec.ops if o[0] == 'sync')
+        self._events = None         # torch events of the ordering points (made on first use, reused step after step)
         self._bases = (ctypes.c_void_p * len(self.names))()
         self._streams = (ctypes.c_void_p * len(self.stream_names))()
         self._fn = L.lib().vqa_run_plan
@@ -205,7 +318,15 @@ class Plan:
         s[0] = L._raw_stream()
         for i, h in enumerate(side_streams):
             s[i + 1] = h
-        status = self._fn(self.words, self.n_words, b, len(self.names), s, len(self.stream_names))
+        ev = None
+        if OWN_EVENTS and self.n_syncs:
+            if self._events is None:
+                evs = [torch.cuda.Event() for _ in range(self.n_syncs)]
+                for e in evs:
+                    e.record()                                   # (a torch event has no handle before its first record)
+                self._events = (evs, (ctypes.c_void_p * self.n_syncs)(*[e.cuda_event for e in evs]))
+            ev = self._events[1]
+        status = self._fn(self.words, self.n_words, b, len(self.names), s, len(self.stream_names), ev, self.n_syncs if ev else 0)
         if status != 0:
             raise L.VqaHipError(f'vqa_run_plan failed: status {status & 255} at op {status >> 8} of {self.n_ops}')
 

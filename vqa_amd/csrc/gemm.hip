@@ -590,8 +590,16 @@ extern "C" int vqa_fc_bce(void* stream, int dtype, int M, int N, int K, const vo
     if (target && labels) return VQA_ERR_ARG;
     if (labels && (!scores || L < 1)) return VQA_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int cap = vqa_fc_bce_part(M, N);
-    if (hipMemsetAsync(part, 0, (size_t)cap * sizeof(double), s) != hipSuccess) return VQA_ERR_LAUNCH;
+    // workgroups (= loss partials) of the GEMM that launch<> will pick: only those slots, and the M row corrections of
+    // the sparse form behind them, are summed - no fill of the scratch on the critical chain (it was a memset)
+    long tiles;
+    if (dtype == VQA_BF16) {
+        const long big = (long)((M + 127) / 128) * ((N + 127) / 128), small = (long)((M + 31) / 32) * ((N + 31) / 32);
+        tiles = (small <= 256 && K <= 1024) ? small : (big >= 160 ? big : (long)((M + 63) / 64) * ((N + 63) / 64));
+    } else {
+        tiles = (long)((N + BN - 1) / BN) * ((M + BM - 1) / BM);
+    }
+    if (tiles + M > vqa_fc_bce_part(M, N)) return VQA_ERR_ARG;
     GemmArgs g{M, N, K, A, lda, W, ldw, logits, ldc, nullptr, nullptr, 1, 2, 0, nullptr, 0, nullptr, K,
                target, ldt, dlogits, ldd, part};
     int st;
@@ -601,8 +609,8 @@ extern "C" int vqa_fc_bce(void* stream, int dtype, int M, int N, int K, const vo
     if (st != VQA_OK) return st;
     if (labels)
         hipLaunchKernelGGL(fc_bce_sparse_fix, dim3((M + 3) / 4), dim3(256), 0, s, logits, ldc, labels, scores, M, N, L,
-                           dlogits, ldd, part + (cap - M));
-    hipLaunchKernelGGL(fc_bce_final, dim3(1), dim3(64), 0, s, part, cap, loss);
+                           dlogits, ldd, part + tiles);
+    hipLaunchKernelGGL(fc_bce_final, dim3(1), dim3(64), 0, s, part, (int)(tiles + (labels ? M : 0)), loss);
     CHECK_LAUNCH();
     return VQA_OK;
 }

@@ -223,6 +223,7 @@ class Trainer:
         self.opt = FlatAdamax(self.flat, lr=lr, max_norm=max_norm)
         self.criterion = SoftScoreBCELoss()
         self._marks, self._mark_i = [], 0           # one event per step in flight (a ring of MAX_AHEAD)
+        self._one = torch.ones((), device=self.flat.flat.device)
 
     def step(self, images, questions, target, flip=True, dropout_noise=None):
         """The step runs on a high-priority HIP stream of its own, ordered after and before the caller's current
@@ -278,8 +279,9 @@ class Trainer:
             loss = self.criterion(logits, target)
         # The step is host-bound (~150 launches): with autograd's worker thread off, the backward's Python code runs
         # on this thread - no hand-over per node (issue time 4.17 -> 3.72 ms per step)
+        # (the root gradient is a resident 1.0: loss.backward() alone would fill a fresh one every step)
         with torch.autograd.set_multithreading_enabled(False):
-            loss.backward()
+            loss.backward(self._one)
         ops.join_deferred()
         if not self.buckets.active:
             self.flat.collect()

@@ -617,7 +617,7 @@ def _train_forward(images, first, params, buffers, padding, pool_mode, dtype, mi
     if dtype != torch.float32:
         B, PH, PW, C = x.shape
         L.call('vqa_cast_pad', L.dt(x), L.F32, x, B * PH * PW, C, C, out, C, None)
-    return saved, meta, ysels, wd
+    return saved, meta, ysels, wd, (x if dtype != torch.float32 else None)
 
 
 def _train_backward(dout, saved, ysels, wd, meta, gdsts, dtype, first, mirror):
@@ -698,6 +698,8 @@ class _CnnFunction(torch.autograd.Function):
             pl.run(arena, [images.data_ptr(), out.data_ptr()] + [t.data_ptr() for t in tensors])
             ctx.plan, ctx.meta, ctx.ysel_at = pl, pl.meta, pl.ysel_at
             ctx.save_for_backward(arena, images, *params)
+            if 'lowp' in pl.exports:
+                out._vqa_lowp = pl.view(arena, 'lowp').view(B, ko, 256)
             return out
         rec = None
         if P.ENABLED and L._PROFILE is None and P.recording() is None:
@@ -708,8 +710,10 @@ class _CnnFunction(torch.autograd.Function):
                 rec.bind(f't{i}', t)
         if rec is not None:
             with rec:
-                saved, meta, ysels, wd = _train_forward(images, first, params, buffers, padding, pool_mode, dtype,
-                                                        mirror, out)
+                saved, meta, ysels, wd, lowp = _train_forward(images, first, params, buffers, padding, pool_mode,
+                                                              dtype, mirror, out)
+                if lowp is not None:
+                    rec.export('lowp', lowp)
                 if first:
                     saved[0] = None                              # (layer 1's input is the image: an external base)
                 for i, t in enumerate(saved):
@@ -726,14 +730,16 @@ class _CnnFunction(torch.autograd.Function):
             if first:
                 saved[0] = images
         else:
-            saved, meta, ysels, wd = _train_forward(images, first, params, buffers, padding, pool_mode, dtype, mirror,
-                                                    out)
+            saved, meta, ysels, wd, lowp = _train_forward(images, first, params, buffers, padding, pool_mode, dtype,
+                                                          mirror, out)
             ctx.fwd_table = None
         ctx.plan = None
         ctx.ysel_at = [li for li in range(10) if ysels[li] is not None]
         ctx.wd_at = [li for li in range(10) if wd[li] is not None]
         ctx.save_for_backward(*saved, *params, *[ysels[li] for li in ctx.ysel_at], *[wd[li] for li in ctx.wd_at])
         ctx.meta = meta
+        if lowp is not None:
+            out._vqa_lowp = lowp.view(B, ko, 256)            # the MFMA-dtype copy the head's GEMMs take (no second cast)
         return out
 
     @staticmethod

@@ -256,4 +256,7 @@ class GRU(nn.Module):
         h_last, h_seq, h_seq_t = _GruFunction.apply(questions_batch, dtype, self.word_embedding.weight, *e.layer(0))
         for k in range(1, e.num_layers):                    # stacked layers (no dropout between them: nn.GRU default)
             h_last, h_seq, h_seq_t = _GruStackedFunction.apply(h_seq, h_seq_t, dtype, *e.layer(k))
+        if dtype != torch.float32:
+            T, B = questions_batch.shape[1], questions_batch.shape[0]
+            h_last._vqa_lowp = h_seq_t[(T - 1) * B:]        # the recurrence's own MFMA-dtype h_T (for the head's GEMMs)
         return h_last                                       # gru.py:105: the top layer's hidden state after token T

@@ -75,10 +75,24 @@ def alpha_dropout_noise(keep, p=0.5):
     return keep * a, (keep - 1.0) * (alpha * a) + alpha * a * p
 
 
+def _lowp_hint(t, shape, dtype):
+    """The MFMA-dtype copy of an encoder output that its producer attached to it (`_vqa_lowp`), if it fits."""
+    h = getattr(t, '_vqa_lowp', None)
+    if (h is not None and dtype != torch.float32 and h.dtype == dtype and tuple(h.shape) == tuple(shape) and
+            h.is_contiguous() and h.device == t.device):
+        return h
+    return None
+
+
 HEAD_LAYERS = ['linear_inside_relu_attention', 'linear_after_relu_attention', 'linear_inside_relu_image',
                'linear_inside_relu_question', 'linear_inside_relu_last', 'fc']
 
 
+# VQA_HEAD_DQ_STREAM=1: the question encoder's gradient (three launches that only its BPTT waits for) is formed on the
+# question encoder's stream instead of the chain that leads to the CNN's backward.  Off: measured SLOWER (same-box A/B,
+# 4 alternations of 60 steps: 4.169 vs 4.139 ms/step) - the two event hops between hardware queues cost the chain more
+# than three 6 us kernels do.
+HEAD_DQ_STREAM = os.environ.get('VQA_HEAD_DQ_STREAM', '0') != '0'
 # Head parameter gradients on the weight-gradient stream (see _HeadFunction.backward); VQA_HEAD_WGRAD_STREAM=0: inline
 HEAD_WGRAD_STREAM = os.environ.get('VQA_HEAD_WGRAD_STREAM', '1') != '0'
 
@@ -104,8 +118,13 @@ class _HeadFunction(torch.autograd.Function):
                                           (v_q, g_q, True), (v_last, g_last, True), (v_fc, g_fc, True)], dtype)
         (W_att, W_att_T), (w_s, _), (W_img, W_img_T), (W_q, W_q_T), (W_last, W_last_T), (W_fc, W_fc_T) = wn
 
-        v_t = ops.cast_pad(v.reshape(B * K, D), dtype)
-        q_t = ops.cast_pad(q, dtype)
+        # the encoders hand over the MFMA-dtype copies they already hold (the last block's bf16 output, the recurrence's
+        # bf16 h_T) beside their f32 outputs: two cast kernels less on the chain between the CNN's forward and backward
+        v_t = _lowp_hint(v, (B, K, D), dtype)
+        v_t = v_t.reshape(B * K, D) if v_t is not None else ops.cast_pad(v.reshape(B * K, D), dtype)
+        q_t = _lowp_hint(q, (B, H), dtype)
+        if q_t is None:
+            q_t = ops.cast_pad(q, dtype)
         qa = ops.gemm(q_t, W_att[:, D:], bias=b_att)                                        # [B,H]
         a = ops.gemm(v_t, W_att[:, :D], out_dtype=dtype, rowadd=qa, group=K, act=act)       # [B*K,H]
         p = torch.empty(B, K, device=dev, dtype=torch.float32)
@@ -133,6 +152,7 @@ class _HeadFunction(torch.autograd.Function):
                               *[t for t in (mask1, mask2) if t is not None], *([dl] if dl is not None else []))
         ctx.dims, ctx.dtype, ctx.has_masks = (B, K, D, H, C), dtype, (mask1 is not None, mask2 is not None)
         ctx.act = act
+        ctx.q_stream = getattr(q, '_vqa_stream', None)
         ctx.fused_loss = dl is not None
         ctx.set_materialize_grads(False)
         return logits, loss
@@ -168,15 +188,28 @@ class _HeadFunction(torch.autograd.Function):
         dpv, dpq = new(B, H), new(B, H)
         L.call('vqa_hadamard_bwd', L.dt(dpv), dm0, fv, fq, mask1, B * H, dpv, dpq, act)
         dvhat = ops.gemm(dpv, W_img_T)                                           # [B,D]
-        dq = ops.gemm(dpq, W_q_T)                                                # [B,H]
         dv = new(B * K, D, dt=torch.float32)
         dpre_a = new(B * K, H)
         dws_part = new(B, H, dt=torch.float32)
         L.call('vqa_attn_bwd', L.dt(a), a, w_s, v, p, dvhat, B, K, H, D, dv, dpre_a, dws_part, act)
         ops.gemm(dpre_a, W_att_T[:D], out=dv, accumulate=True)                   # += dpre_a @ W_v
-        dqa, dqa_t = new(B, H, dt=torch.float32), new(B, H)
-        L.call('vqa_group_sum', L.dt(dpre_a), dpre_a, B, K, H, dqa, dqa_t)
-        ops.gemm(dqa_t, W_att_T[D:], out=dq, accumulate=True)                    # += dqa @ W_q-part
+        # dv is what the image encoder's backward - the critical chain - waits for.  The question encoder's gradient
+        # (three more launches) is formed on the stream its backward will run on (ctx.q_stream: the question encoder's
+        # side stream, where the recurrence's BPTT ends 1.2 ms before the CNN's backward does)
+        qs = ctx.q_stream if (HEAD_DQ_STREAM and ctx.q_stream is not None) else None
+        main = torch.cuda.current_stream()
+        if qs is not None and qs != main:
+            qs.wait_event(main.record_event())
+            for t in (dpq, dpre_a, W_q_T, W_att_T):
+                t.record_stream(qs)
+        else:
+            qs = None
+        with torch.cuda.stream(qs if qs is not None else main):
+            dq = ops.gemm(dpq, W_q_T)                                            # [B,H]
+            dqa, dqa_t = new(B, H, dt=torch.float32), new(B, H)
+            L.call('vqa_group_sum', L.dt(dpre_a), dpre_a, B, K, H, dqa, dqa_t)
+            ops.gemm(dqa_t, W_att_T[D:], out=dq, accumulate=True)                # += dqa @ W_q-part
+        dq_done = qs.record_event() if qs is not None else None
 
         # ---- parameter gradients: nothing downstream in this backward needs them, so they run on the weight-gradient
         # stream beside the encoders' backward (ops.defer_join: joined before backward() returns / before a bucket
@@ -203,6 +236,8 @@ class _HeadFunction(torch.autograd.Function):
             side = _wgrad_stream(dev)
             cur = torch.cuda.current_stream()
             side.wait_event(cur.record_event())
+            if dq_done is not None:
+                side.wait_event(dq_done)                                         # (dqa / dqa_t come from that stream)
             # Autograd hands the returned gradients to each parameter's AccumulateGrad node right after this function,
             # on THIS stream.  With p.grad None and no tensor hooks that node only adopts the tensor (no kernel), so
             # the side-stream work may still be running and is joined later (ops.defer_join).  With an existing
@@ -228,7 +263,12 @@ class _HeadFunction(torch.autograd.Function):
                 for t in [x for pair in wn for x in pair] + [db_att, db_img, db_q, db_last]:
                     t.record_stream(cur)                                         # (allocated on that stream, read on this)
         else:
+            if dq_done is not None:
+                torch.cuda.current_stream().wait_event(dq_done)
             wn, db_att, db_img, db_q, db_last = weights()
+        if dq_done is not None:
+            for t in (dqa, dqa_t, dq):
+                t.record_stream(main)           # (made on the question stream; dq travels through autograd from here)
         (dg_att, dv_att), (dg_s, dv_s), (dg_img, dv_img), (dg_q, dv_q), (dg_last, dv_last), (dg_fc, dv_fc) = wn
         return (dv.reshape(B, K, D), dq, None, None, None, dg_att, dv_att, db_att, dg_s, dv_s, dg_img, dv_img, db_img,
                 dg_q, dv_q, db_q, dg_last, dv_last, db_last, dg_fc, dv_fc, None)
@@ -313,6 +353,7 @@ class VQA(nn.Module):
             images_representation = self.cnn(images_batch, mirror)      # [B, k, d]
             cur.wait_stream(side)
             questions_representation.record_stream(cur)
+            questions_representation._vqa_stream = side      # (where its backward will run: _HeadFunction.backward)
         else:
             images_representation = self.cnn(images_batch, mirror)
             questions_representation = self.gru(questions_batch)

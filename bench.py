@@ -136,11 +136,24 @@ def pmc_traffic(kernel):
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this bench; counters are in KB).  gfx950 correction of
     MI355X_MICROARCH.md (HBM): FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane reads at 64 bytes, so it is
     doubled; WRITE_SIZE is exact for 16/8-byte streaming stores.  None when no profile is committed for the kernel."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_traffic.json')
+    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', name)
+        try:
+            rec = json.load(open(path))[kernel]
+            return round((2.0 * rec['FETCH_SIZE'] + rec['WRITE_SIZE']) * 1024.0 / rec['launches'])
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            continue
+    return None
+
+
+def pmc_mfma(kernel):
+    """MFMA-pipe busy fraction of a kernel family from the committed counter passes (scripts/pmc_mfma.sh ->
+    profiles/r03_pmc_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES over the SIMD-cycles of the launches), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_pmc_mfma.json')
+    alias = {'conv3x3_wgrad_deep': 'conv3x3_wgrad_deep(Cin>=32,Cout>=64)', 'conv3x3_wgrad': 'conv3x3_wgrad_shallow'}
     try:
-        rec = json.load(open(path))[kernel]
-        return round((2.0 * rec['FETCH_SIZE'] + rec['WRITE_SIZE']) * 1024.0 / rec['launches'])
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return json.load(open(path))[alias.get(kernel, kernel)]['mfma_busy_frac']
+    except (OSError, KeyError, ValueError):
         return None
 
 
@@ -225,7 +238,11 @@ def roofline_leg(trainer, batch, precision='bf16'):
     dom = max(priced, key=lambda k: fam[k]['ms'])
     out = dict(kernel=dom, traffic=pmc_traffic(dom), **priced[dom])
     by_kernel = {k: {kk: v[kk] for kk in ('bound', 'frac', 'achieved', 'unit', 'kernel_ms_per_step', 'launches_per_step')}
-                 for k, v in sorted(priced.items(), key=lambda kv: -fam[kv[0]]['ms'])[:8]}
+                 for k, v in sorted(priced.items(), key=lambda kv: -fam[kv[0]]['ms'])[:9]}
+    for k, v in by_kernel.items():
+        busy = pmc_mfma(k)
+        if busy is not None:
+            v['pmc_mfma_busy'] = busy           # rocprofv3 counters: fraction of SIMD-cycles with the MFMA pipe busy
     out['per_launch'] = [f"{name}[{tag['kind']}] {tag['shape']:>18s} {ms:7.3f} ms {tag['flops'] / ms / 1e9:8.1f} TF/s "
                          f"{tag['bytes'] / ms / 1e6:8.1f} GB/s"
                          for name, recs in prof.items() for ms, tag in recs if tag]

@@ -19,6 +19,6 @@ PY
 for rep in 1 2; do
     run plain_$rep X=1 -- || exit 1
     run fb_$rep X=1 -- --force-buckets || exit 1
-    run fb_nofold_$rep VQA_DP_FOLD_STREAMS=0 -- --force-buckets || exit 1
+    run fb_fold_$rep VQA_DP_FOLD_STREAMS=1 -- --force-buckets || exit 1
     run fb_hookstream_$rep VQA_DP_ISSUE_FROM_PRODUCER=0 -- --force-buckets || exit 1
 done

@@ -144,6 +144,12 @@ def _plan(*key):
     return _plans[key]
 
 
+def _wgrad_family(cin, cout):
+    """bench.py's roofline leg prices the weight gradient in its two regimes: the conv3x3_wgrad<32, 64> instantiations
+    (Cin >= 32 and Cout >= 64: MFMA-bound) apart from the shallow, HBM-bound ones."""
+    return 'conv3x3_wgrad_deep' if (cin >= 32 and cout >= 64) else 'conv3x3_wgrad'
+
+
 def wgrad_rows(x, dy):
     """G of conv_wgrad for these shapes (rows of its partial-slab workspace)."""
     return _wgrad_geom(x, dy)[2]
@@ -183,13 +189,15 @@ def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None, defer=None, part_
     isc, ish = in_coeffs if in_coeffs is not None else (None, None)
     if part_out is not None:
         assert tuple(part_out.shape) == (G, cout, 9, cin) and part_out.is_contiguous()
-        tag = lambda: _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), cout * cin_real * 36)
+        tag = lambda: _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), cout * cin_real * 36,
+                                kernel=_wgrad_family(cin, cout))
         L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part_out, None, G, B, IH, IW, cin, cin_real,
                OH, OW, cout, pad, R, CW, isc, ish, tag=tag)
         return None
     part = P.empty((G, cout, 9, cin), torch.float32, x.device)
     dw = out if out is not None else P.empty((cout, cin_real, 3, 3), torch.float32, x.device)
-    tag = lambda: _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4)
+    tag = lambda: _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4,
+                            kernel=_wgrad_family(cin, cout))
     L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw if defer is None else None, G, B, IH, IW, cin, cin_real,
            OH, OW, cout, pad, R, CW, isc, ish, tag=tag)
     if defer is not None:

@@ -171,6 +171,10 @@ def _wgrad_geom(x, dy):
     lds = (R + 2) * (CW + 2) * pxb + (-(-R * CW // kc) * kc) * (dyb + 4) + 8 * ck
     # resident workgroups per CU: register-limited waves/SIMD of the instantiation, then LDS
     waves = 4 if cow == 16 else 2
+    if WGRAD_COF4 and cow == 64 and ck == 32 and esz == 2:
+        # the four-fragment form (conv.hip, COFX = 4): 360 registers = one wave per SIMD, and its cross-slice combine
+        # buffer (73.7 KB) is the floor of its LDS
+        waves, lds = 1, max(lds, 2 * 9 * 4 * 1024)
     per_cu = max(1, min(waves, (160 * 1024) // lds))
     if per_cu - WGRAD_RESERVE >= 2:
         per_cu -= WGRAD_RESERVE
@@ -525,6 +529,7 @@ DEFER_WGRAD_REDUCE = os.environ.get('VQA_DEFER_WGRAD_REDUCE', '0') != '0'
 BWD_SLICES = int(os.environ.get('VQA_BWD_SLICES', '0'))
 BWD_SLICE_MIN_MB = float(os.environ.get('VQA_BWD_SLICE_MIN_MB', '300'))
 WGRAD_RESERVE = int(os.environ.get('VQA_WGRAD_RESERVE', '0'))
+XX
 # The first layer's weight gradient is the LAST kernel of the backward and depends only on the data gradient above it
 # (through BatchNorm 1's c1, c2).  On the weight-gradient stream it queued behind the weight gradient (last slice) and
 # the slab sum of the layer above while the main stream had nothing left to do; on the main stream it starts at once
@@ -565,7 +570,8 @@ def _wgrad_stream(dev):
 def _knobs():
     """Everything in this module the recorded launch sequence depends on (part of every plan key)."""
     return (WGRAD_STREAM, FUSE_BN_FWD, FUSE_BN_BWD, FUSE_FIRST_BN, FUSE_POOL_BWD, DEFER_WGRAD_REDUCE, BWD_SLICES,
-            BWD_SLICE_MIN_MB, WGRAD_RESERVE, FIRST_WGRAD_MAIN, FIRST_RESERVE, WGRAD_HOLD_FROM, WGRAD_RELEASE_AT)
+            BWD_SLICE_MIN_MB, WGRAD_RESERVE, FIRST_WGRAD_MAIN, FIRST_RESERVE, WGRAD_HOLD_FROM, WGRAD_RELEASE_AT,
+            WGRAD_COF4)
 
 
 def out_regions(size, padding):

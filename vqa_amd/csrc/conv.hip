@@ -778,14 +778,21 @@ __host__ __device__ constexpr int dy_stride(int esz, int cow) {
 // (wcg), i.e. 9 x COF accumulator tiles; waves left over split the pixel reduction (wk).  Per 32-pixel step a wave
 // then reads 9 patch fragments + COF dy fragments for 9 x COF MFMAs - the patch fragments, which dominate the LDS
 // traffic, are no longer re-read by every output-channel wave.
-template <typename T, int CK, int COW, bool XF>
+// COFX = 4 (the MFMA-bound <32, 64> instantiations): FOUR output-channel fragments per wave - 36 accumulator tiles, the
+// two wave pairs split the pixel reduction.  Per 32-pixel step a wave then reads 18 + 8 transposing 8-byte fragments for
+// 36 MFMAs (0.72 LDS reads per MFMA) where the two-fragment form reads 18 + 4 for 18 (1.22): that form was bound by the
+// LDS pipe (352 cycles against 288 of MFMA per step of a workgroup).  MEASURED SLOWER and off by default
+// (VQA_WGRAD_COF4=1 turns it on): 144 accumulator + 216 other registers = 360 per lane, ONE wave per SIMD where the
+// two-fragment form (224) has two, and with one wave nothing hides the LDS latency of the fragment reads -
+// 56x56 64->64 0.088 -> 0.113 ms, 28x28 128->128 0.088 -> 0.114, 10x10 256->256 0.066 -> 0.085; step 4.056 -> 4.119 ms.
+template <typename T, int CK, int COW, bool XF, int COFX = 0>
 __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     constexpr int VEC = Mma<T>::VEC, KC = 4 * VEC;
     constexpr int PXB = pix_stride(CK * (int)sizeof(T));
     constexpr int DYB = dy_stride((int)sizeof(T), COW);
     constexpr int VPP = CK * (int)sizeof(T) / 16;
     constexpr int CF = CK / 16;                         // input-channel fragments of the workgroup
-    constexpr int COF = COW >= 32 ? 2 : 1;              // output-channel fragments per wave
+    constexpr int COF = COFX ? COFX : (COW >= 32 ? 2 : 1);   // output-channel fragments per wave
     constexpr int NCG = COW / 16 / COF;                 // output-channel fragment groups
     constexpr int nwk = 4 / (CF * NCG);                 // pixel-reduction slices
     static_assert(CF * NCG * nwk == 4, "4 waves");
@@ -1252,12 +1259,12 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int MT = R * CW, PPIX = (R + 2) * (CW + 2);
     int status = VQA_ERR_ARG;
-    auto go = [&](auto kern, int CK, int esz) {
+    auto go = [&](auto kern, int CK, int esz, int cofx = 0) {
         const int KC = 64 / esz;
         const int MTP = (MT + KC - 1) / KC * KC;
         size_t lds = (size_t)(PPIX * pix_stride(CK * esz) + 15) / 16 * 16 + (size_t)MTP * dy_stride(esz, COW) +
                      (size_t)MTP * 4 + (size_t)2 * CK * 4;                         // + pixel -> patch table, XF coeffs
-        const int cof = COW >= 32 ? 2 : 1, roles = (CK / 16) * (COW / 16 / cof), nwk = 4 / roles;
+        const int cof = cofx ? cofx : (COW >= 32 ? 2 : 1), roles = (CK / 16) * (COW / 16 / cof), nwk = 4 / roles;
         const size_t red = (size_t)(nwk - 1) * roles * 9 * cof * 1024;              // cross-slice combine buffer
         if (lds < red) lds = red;
         if (lds > 160 * 1024) return VQA_ERR_ARG;
@@ -1272,7 +1279,11 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     (xf ? go(conv3x3_wgrad<T, CK, COW_, true>, CK, ESZ) : go(conv3x3_wgrad<T, CK, COW_, false>, CK, ESZ))
 #define GO_COW(T, CK, ESZ) \
     (COW == 64 ? GO_XF(T, CK, 64, ESZ) : (COW == 32 ? GO_XF(T, CK, 32, ESZ) : GO_XF(T, CK, 16, ESZ)))
-        if (Cin % 32 == 0) status = GO_COW(bf16, 32, 2);
+        // VQA_WGRAD_COF4 (read once; default off: slower, see the kernel): the four-fragment form of <32, 64>
+        static const bool cof4 = [] { const char* e = getenv("VQA_WGRAD_COF4"); return e ? atoi(e) != 0 : false; }();
+        if (Cin % 32 == 0 && COW == 64 && cof4)
+            status = xf ? go(conv3x3_wgrad<bf16, 32, 64, true, 4>, 32, 2, 4) : go(conv3x3_wgrad<bf16, 32, 64, false, 4>, 32, 2, 4);
+        else if (Cin % 32 == 0) status = GO_COW(bf16, 32, 2);
         else if (Cin == 16) status = GO_COW(bf16, 16, 2);
     } else if (dtype == VQA_F32) {
         if (MT > 128 || PPIX > 320) return VQA_ERR_ARG;

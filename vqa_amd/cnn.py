@@ -529,7 +529,9 @@ DEFER_WGRAD_REDUCE = os.environ.get('VQA_DEFER_WGRAD_REDUCE', '0') != '0'
 BWD_SLICES = int(os.environ.get('VQA_BWD_SLICES', '0'))
 BWD_SLICE_MIN_MB = float(os.environ.get('VQA_BWD_SLICE_MIN_MB', '300'))
 WGRAD_RESERVE = int(os.environ.get('VQA_WGRAD_RESERVE', '0'))
-XX
+# the deep weight gradient's four-output-fragment form (read by the library from the same variable; measured slower:
+# one wave per SIMD - conv.hip)
+WGRAD_COF4 = os.environ.get('VQA_WGRAD_COF4', '0') != '0'
 # The first layer's weight gradient is the LAST kernel of the backward and depends only on the data gradient above it
 # (through BatchNorm 1's c1, c2).  On the weight-gradient stream it queued behind the weight gradient (last slice) and
 # the slab sum of the layer above while the main stream had nothing left to do; on the main stream it starts at once

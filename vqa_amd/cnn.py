@@ -706,12 +706,15 @@ class _CnnFunction(torch.autograd.Function):
         B, _, IH, IW = images.shape
         ko = out_regions(IH, padding) * out_regions(IW, padding)
         out = torch.empty(B, ko, 256, device=dev, dtype=torch.float32)
-        key = ('cnn.fwd', dev.index, tuple(images.shape), images.dtype, padding, pool_mode, dtype, mirror, first, _knobs())
+        # (the batch-flip flag is a run-time value of the plan, not part of its key: the mirrored and the plain step are
+        # the same launches but for that one integer of the two first-layer kernels)
+        key = ('cnn.fwd', dev.index, tuple(images.shape), images.dtype, padding, pool_mode, dtype, first, _knobs())
         ctx.cfg, ctx.first, ctx.mirror, ctx.key = cfg, first, mirror, key
         pl = P.lookup(key)
         if pl is not None:
             arena = pl.arena(dev)
-            pl.run(arena, [images.data_ptr(), out.data_ptr()] + [t.data_ptr() for t in tensors])
+            pl.run(arena, [images.data_ptr(), out.data_ptr()] + [t.data_ptr() for t in tensors],
+                   patch={'mirror': int(mirror)})
             ctx.plan, ctx.meta, ctx.ysel_at = pl, pl.meta, pl.ysel_at
             ctx.save_for_backward(arena, images, *params)
             if 'lowp' in pl.exports:
@@ -724,6 +727,7 @@ class _CnnFunction(torch.autograd.Function):
             rec.bind('out', out)
             for i, t in enumerate(tensors):
                 rec.bind(f't{i}', t)
+            rec.patchable('mirror', 'vqa_conv3x3_first_fwd', 17)
         if rec is not None:
             with rec:
                 saved, meta, ysels, wd, lowp = _train_forward(images, first, params, buffers, padding, pool_mode,
@@ -793,7 +797,8 @@ class _CnnFunction(torch.autograd.Function):
             arena_b = pl.arena(dev)
             # (bases in the order the recording bound them: fwd arena, [the image: first-layer kernels only], dout, grads)
             pl.run(arena_b, [arena.data_ptr()] + ([images.data_ptr()] if ctx.first else []) +
-                   [dout.data_ptr(), gbase.data_ptr()], [side.cuda_stream] if side is not None else [])
+                   [dout.data_ptr(), gbase.data_ptr()], [side.cuda_stream] if side is not None else [],
+                   patch={'mirror': int(ctx.mirror)})
             return (None, None, *gdsts, *([None] * 30))
         # ---- launch by launch (and recorded, when the forward pass has a plan to record against)
         if ctx.plan is not None:
@@ -822,6 +827,8 @@ class _CnnFunction(torch.autograd.Function):
             rec.bind('grads', gbase)
             if side is not None:
                 rec.stream('wgrad', side)
+            rec.patchable('mirror', 'vqa_conv3x3_first_wgrad', 14)
+            rec.patchable('mirror', 'vqa_conv3x3_first_wgrad_bn', 21)
 
         def run():
             if not flat:

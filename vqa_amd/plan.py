@@ -72,6 +72,7 @@ class Recorder:
         self.streams = {L._raw_stream(): 0}
         self.stream_names = ['main']
         self.exports = {}           # name -> (alloc id, delta, shape, dtype)
+        self.patches = {}           # name -> [(entry, argument index)]
         self.ok = True
 
     # ---- bases
@@ -152,6 +153,12 @@ class Recorder:
 
     def sync(self, waiter_raw, signal_raw):
         self.ops.append(('sync', self.streams[waiter_raw], self.streams[signal_raw]))
+
+    def patchable(self, name, entry_name, arg_index):
+        """Declare argument `arg_index` (0 = first after the stream) of every recorded call of `entry_name` a run-time
+        value `name`: Plan.run(patch={name: int}) overwrites it before the replay (the batch-flip flag of the
+        first-layer kernels: one plan serves the mirrored and the plain step)."""
+        self.patches.setdefault(name, []).append((L.lib().vqa_plan_opcode(entry_name.encode()), arg_index))
 
     # ---- layout + encoding
     def _layout(self):
@@ -236,13 +243,19 @@ class Recorder:
             kind, b, delta = ref
             return (0 << 48) | (offsets[b] + delta) if kind == 'a' else (b << 48) | delta
         words = []
+        spots = {name: [] for name in self.patches}     # word indices (in the body) of the patchable values
         for o in self.ops:
             if o[0] == 'sync':
                 words += [OP_SYNC, o[1], 1, K_INT, o[2]]
                 continue
             _, entry, sidx, enc = o
             words += [entry, sidx, len(enc)]
-            for kind, val in enc:
+            for ai, (kind, val) in enumerate(enc):
+                for name, targets in self.patches.items():
+                    if (entry, ai) in targets:
+                        if kind != K_INT:
+                            raise PlanError(f'patchable argument {name} is not an integer')
+                        spots[name].append(len(words) + 1)
                 if kind == K_PTR:
                     words += [K_PTR, word(val)]
                 elif kind == K_PTRARR:
@@ -253,6 +266,7 @@ class Recorder:
                     words += [kind, val]
         exports = {name: (offsets[a] + delta, shape, dtype) for name, (a, delta, shape, dtype, _, _) in self.exports.items()}
         live = [(ptr, nbytes, offsets[a] + delta) for (a, delta, _, _, ptr, nbytes) in self.exports.values()]
+        self.spots = spots
         return words, size, exports, live
 
     # ---- context
@@ -289,6 +303,7 @@ class Plan:
         # handed out again (to the backward's incoming gradient, say)
         self.table = live
         self.n_ops = len(rec.ops)
+        self.spots = {name: [i + 2 for i in idx] for name, idx in rec.spots.items()}    # (+ magic, op count)
         self.n_syncs = sum(1 for o in rec.ops if o[0] == 'sync')
         self._events = None         # torch events of the ordering points (made on first use, reused step after step)
         self._bases = (ctypes.c_void_p * len(self.names))()
@@ -305,9 +320,14 @@ class Plan:
             n *= s
         return arena[off:off + n * dtype.itemsize].view(dtype).view(shape)
 
-    def run(self, arena, bases, side_streams=()):
+    def run(self, arena, bases, side_streams=(), patch=None):
         """bases: data pointers (ints) of the external bases in the order they were bound; side_streams: raw handles
-        of the named side streams in the order they were declared.  The current stream is stream 0."""
+        of the named side streams in the order they were declared.  The current stream is stream 0.
+        patch: {name: int} for the arguments the recording declared patchable."""
+        if patch:
+            for name, value in patch.items():
+                for i in self.spots[name]:
+                    self.words[i] = value
         b = self._bases
         b[0] = arena.data_ptr()
         if len(bases) != len(self.names) - 1 or len(side_streams) != len(self.stream_names) - 1:

@@ -14,6 +14,10 @@ all: $(LIB)
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
+# one typed thunk per stream-taking entry point, generated from the header's declarations
+$(CSRC)/plan_thunks.inc: include/vqa_hip.h scripts/gen_plan_thunks.py
+	python3 scripts/gen_plan_thunks.py
+
 $(CSRC)/plan.o: $(CSRC)/plan_thunks.inc include/vqa_hip.h
 
 $(LIB): $(OBJS)

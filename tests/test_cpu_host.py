@@ -127,3 +127,45 @@ def test_every_stream_entry_point_has_a_plan_thunk():
             'vqa_plan_opcode',) and not name.endswith(('_rows', '_plan', '_part', '_ws_bytes'))
         op = lib.vqa_plan_opcode(name.encode())
         assert (op >= 0) == takes_stream, name
+
+
+def test_plan_thunks_are_current():
+    """csrc/plan_thunks.inc must be what scripts/gen_plan_thunks.py makes of the header as it stands (a prototype
+    changed without regenerating would cast a replayed call's arguments to the old types)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('gen_plan_thunks', os.path.join(root, 'scripts', 'gen_plan_thunks.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(os.path.join(root, 'vqa_amd', 'csrc', 'plan_thunks.inc')) as f:
+        assert f.read() == mod.generate()
+
+
+def test_arena_layout_reuses_dead_temporaries_safely():
+    """plan.Recorder._layout: bytes of a temporary are handed out again after its last op; one that a side stream
+    touches stays reserved until the main stream has waited for that stream; one FIRST touched on a side stream only
+    takes bytes released before that stream last waited for the main stream; exported ones are never recycled."""
+    from vqa_amd import plan as P
+
+    class R(P.Recorder):
+        def __init__(self):
+            self.ops, self.allocs, self.exports = [], [], {}
+    MB = 1 << 20
+    r = R()
+    r.ops = [('call', 0, 0, [])] * 10
+    r.ops[2] = ('sync', 1, 0)                    # stream 1 waits for the main stream
+    r.ops[6] = ('sync', 0, 1)                    # the main stream waits for stream 1
+    r.allocs = [[0, 10 * MB, 0, 1, {0: 0}, False],        # main only, dead after op 1
+                [0, 10 * MB, 1, 3, {0: 1, 1: 3}, False],  # read by stream 1 at op 3: reserved until the join at op 6
+                [0, 10 * MB, 3, 4, {1: 4}, False],        # first touched on stream 1 (after its wait at op 2)
+                [0, 4 * MB, 5, 8, {0: 5}, True],          # exported
+                [0, 10 * MB, 7, 9, {0: 7}, False]]
+    offsets, size = r._layout()
+    assert offsets[2] == offsets[0] == 0          # took over the dead main-stream temporary (released before op 2)
+    assert offsets[1] == 10 * MB
+    assert offsets[3] == 20 * MB                  # nothing free at op 5: both side-stream temporaries still reserved
+    assert offsets[4] == 0 and size == 24 * MB    # after the join everything but the exported one is free again
+    # without the wait at op 2 the side-stream temporary may not take over main-stream bytes
+    r.ops[2] = ('call', 0, 0, [])
+    assert r._layout()[0][2] == 20 * MB

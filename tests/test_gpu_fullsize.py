@@ -185,4 +185,13 @@ def test_shapes_beyond_the_32bit_offsets_are_refused():
     with pytest.raises(L.VqaHipError):
         M.conv_fwd(x, wpk, torch.zeros(128, device='cuda'), 128, 0, True)
     del x
+    # the multi-chunk kernel's index products are SIGNED 24-bit multiplies and its quotients come from a
+    # float reciprocal - an image of 2^22 pixels or more is refused at launch (it used to pass a 2^24 guard and would
+    # have read out of range, silently wrong)
+    x = torch.zeros(1, 2049, 2049, 64, device='cuda', dtype=torch.bfloat16)     # 4.2 M pixels, 537 MB
+    w = torch.zeros(64, 64, 3, 3, device='cuda')
+    wpk = M.pack_weights(w, 64, torch.bfloat16, dgrad=False)
+    with pytest.raises(L.VqaHipError):
+        M.conv_fwd(x, wpk, torch.zeros(64, device='cuda'), 64, 0, True)
+    del x
     torch.cuda.empty_cache()

@@ -72,3 +72,30 @@ def test_probe_tr16():
     g, i = lane // 16, lane % 16
     exp = torch.stack([(4 * g + q) * 16 + i for q in range(4)], dim=1).float()
     assert torch.equal(out, exp), out
+
+
+@pytest.mark.parametrize('M,N', [(3072, 300), (37, 5), (1, 1), (64, 64), (100, 33)])
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+def test_cast_transpose(M, N, dt):
+    """vqa_cast_transpose: dst [N][ld] = src [M][lds]^T in the destination dtype, pad columns zero (the GRU's W_ih^T)."""
+    from vqa_amd import ops
+    torch.manual_seed(M + N)
+    src = torch.randn(M, N + 3, device='cuda')[:, :N]                 # a row stride that is not N
+    out = ops.cast_transpose(src, dt)
+    assert out.shape == (N, M) and out.dtype == dt
+    assert torch.equal(out, src.t().to(dt))
+    full = out.as_strided((N, ops.pad8(M)), (out.stride(0), 1))
+    assert float(full[:, M:].abs().max() if ops.pad8(M) > M else 0.0) == 0.0
+
+
+@pytest.mark.parametrize('nwords,offset', [(1, 0), (3, 1), (4, 0), (5, 3), (1027, 2), (3_000_000, 0), (65, 1)])
+def test_zero_fill(nwords, offset):
+    """vqa_zero from any 4-byte aligned address: head words up to the 16-byte boundary, vector body, tail - and nothing
+    outside the range."""
+    from vqa_amd import _lib as L
+    buf = torch.full((nwords + offset + 9,), 7.0, device='cuda')
+    L.call('vqa_zero', buf[offset:], nwords * 4)
+    torch.cuda.synchronize()
+    assert buf[:offset].eq(7).all() and buf[offset:offset + nwords].eq(0).all() and buf[offset + nwords:].eq(7).all()
+    with pytest.raises(L.VqaHipError):
+        L.call('vqa_zero', buf, 6)                                     # not a multiple of 4 bytes

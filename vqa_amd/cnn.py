@@ -495,7 +495,12 @@ def _eval_forward(x, first, params, buffers, padding, pool_mode, dtype):
             y, _ = conv_fwd(x, slabs[li], bf, c, pad, False, cin_real=w.shape[1], relu=True)
         x = bn_act_pool(y, one, zero, pool_mode) if li % 2 == 1 else y       # relu(y) >= 0: pool-only pass
     B, PH, PW, C = x.shape
-    return x.reshape(B, PH * PW, C).float()
+    if x.dtype == torch.float32:
+        return x.reshape(B, PH * PW, C)
+    out = torch.empty(B, PH * PW, C, device=dev, dtype=torch.float32)
+    L.call('vqa_cast_pad', L.dt(x), L.F32, x, B * PH * PW, C, C, out, C, None)
+    out._vqa_lowp = x.reshape(B, PH * PW, C)         # (the head's GEMMs take the bf16 copy as it is)
+    return out
 
 
 # The weight gradient of a layer is off the backward's critical chain (BatchNorm-backward -> dgrad -> next layer's

@@ -64,7 +64,18 @@ int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked,
                     int G, int relu /* 1: y = max(conv + bias, 0) - eval mode with the BatchNorm folded into w, bias */,
                     const float* in_scale, const float* in_shift, const void* bn_y, const float* bn_coef);
 int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW,
-                     int variant /* 0 plain, 1 with in_scale / in_shift, 2 with bn_y / bn_coef */);
+                     int variant /* 0 plain, 1 with in_scale / in_shift, 2 with bn_y / bn_coef, 3 vqa_conv3x3_dgrad_wgrad */);
+/* Both gradients of a pad-0 conv whose input is the BatchNorm + ReLU of the layer below (autograd of cnn.py:24-25, 28-29:
+ * the second conv of a block) from ONE pass over dy and that layer's raw output: the data-gradient call of
+ * vqa_conv3x3_fwd with bn_y / bn_coef (dy = this call's x with Cin channels, dx its y with Cout channels, pad = 2), which
+ * also leaves the conv's weight gradient as G partial slabs wpart [G][Cin][9][Cout] f32 - x = relu(scale*bn_y + shift)
+ * is formed in the epilogue from the values loaded for the sums, bit for bit the input the forward conv saw.  Sum the
+ * slabs with vqa_conv3x3_wgrad_reduce_all (desc: G, Cin, Cout, real input channels of the conv).  bf16, Cin = Cout =
+ * 16 or 32 (all channels in one workgroup); status 1 otherwise.  dx and the sums are bit-identical to vqa_conv3x3_fwd's;
+ * the weight gradient is the same sum in another (fixed) order than vqa_conv3x3_wgrad's. */
+int vqa_conv3x3_dgrad_wgrad(void* stream, int dtype, const void* dy, const void* wpacked, void* dx, float* stats,
+                            float* wpart, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R,
+                            int CW, int G, const void* bn_y, const float* bn_coef);
 
 /* First encoder layer, bf16 path: nn.Conv2d(3, 16, 3, padding=pad) (cnn.py:23) straight from the NCHW image
  * (in_dtype f16 / f32 / bf16; dataset.py:96-98 stores f16) - no NHWC copy, no channel padding.

@@ -388,6 +388,83 @@ def test_dgrad_with_fused_bn_backward_reduction(prec, B, c_lo, c_hi, H, W):
         assert float((out[0][k] - out[1][k]).abs().max()) < 1e-5 * max(scale[k], 1.0) * (n ** 0.5)
 
 
+@pytest.mark.parametrize('B,c,H,W', [(2, 16, 40, 40), (3, 32, 23, 31), (1, 16, 226, 226), (2, 32, 116, 116),
+                                      (5, 16, 9, 20), (1, 32, 3, 3), (64, 16, 37, 50)])
+def test_dgrad_and_wgrad_from_one_kernel(B, c, H, W):
+    """vqa_conv3x3_dgrad_wgrad against the two kernels it replaces (the BST data gradient and the XF weight gradient):
+    dx and the BatchNorm-backward rows bit-identical; the weight gradient equal up to the fp32 summation order of the
+    partial slabs, and exact on integer-valued data (every product and sum exact in f32)."""
+    from vqa_amd import cnn as C
+    dt = torch.bfloat16
+    for exact in (True, False):
+        torch.manual_seed(c + H + exact)
+        w = torch.randn(c, c, 3, 3) / (3 * c ** 0.5)
+        if exact:
+            dy = torch.randint(-3, 4, (B, H - 2, W - 2, c)).to(dt).cuda()
+            y_lo = torch.randint(-4, 5, (B, H, W, c)).to(dt).cuda()
+            coef = torch.stack([torch.randint(1, 3, (c,)).float(), torch.randint(-2, 3, (c,)).float(),
+                                torch.zeros(c), torch.ones(c)]).cuda()
+        else:
+            dy = torch.randn(B, H - 2, W - 2, c).to(dt).cuda()
+            y_lo = (torch.randn(B, H, W, c) * 1.5).to(dt).cuda()
+            coef = torch.stack([torch.rand(c) + 0.5, torch.randn(c) * 0.4, torch.randn(c) * 0.3,
+                                torch.rand(c) + 0.7]).cuda()
+        wd = C.pack_weights(w.cuda(), c, dt, dgrad=True)
+        d_ref, rows_ref = C.conv_fwd(dy, wd, None, c, 2, False, kind='dgrad', bst=(y_lo, coef))
+        dw_ref = C.conv_wgrad(y_lo, dy, c, 0, in_coeffs=(coef[0], coef[1]))
+        dx, rows, part = C.conv_dgrad_wgrad(dy, wd, c, (y_lo, coef), c)
+        dw = torch.full((c, c, 3, 3), float('nan'), device='cuda')
+        C.wgrad_reduce_all([(part, dw, part.shape[0], c, c, c)])
+        assert torch.equal(dx, d_ref)
+        # (the fused form has its own persistent grid: compare the finalized sums, not the rows)
+        assert rows.shape[1:] == rows_ref.shape[1:]
+        s, sr = rows.double().sum(0), rows_ref.double().sum(0)
+        assert float((s - sr).abs().max()) <= 1e-5 * max(float(sr.abs().max()), 1.0) * (B * H * W) ** 0.5
+        if exact:
+            assert torch.equal(dw, dw_ref)
+            xa = torch.relu(y_lo.float() * coef[0] + coef[1]).permute(0, 3, 1, 2).double().cpu()
+            g = dy.float().permute(0, 3, 1, 2).double().cpu()
+            want = torch.nn.grad.conv2d_weight(xa, (c, c, 3, 3), g)
+            assert torch.equal(dw.double().cpu(), want)
+        else:
+            tol = 2e-6 * float(dw_ref.abs().max()) * (B * H * W) ** 0.5
+            assert float((dw - dw_ref).abs().max()) <= tol
+
+
+@pytest.mark.parametrize('streams', [True, False])
+def test_encoder_with_one_kernel_gradients_matches_two(streams, monkeypatch):
+    """Whole encoder, bf16: cnn.FUSE_DGRAD_WGRAD = 32 (blocks 1 and 2, block 1 in batch slices) vs 0."""
+    from vqa_amd import cnn as M, synth
+    sd = {k[4:]: v for k, v in synth.state_dict(42, 64, 50, 30).items() if k.startswith('cnn.')}
+    img = synth.images(8, 3, 224).cuda()
+    monkeypatch.setattr(M, 'WGRAD_STREAM', streams)
+    monkeypatch.setattr(M, 'BWD_SLICES', 2)
+    monkeypatch.setattr(M, 'BWD_SLICE_MIN_MB', 1.0)
+    outs = []
+    for fuse in (32, 0):
+        monkeypatch.setattr(M, 'FUSE_DGRAD_WGRAD', fuse)
+        m = M.CNN(2, 'max', precision='bf16')
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        out = m(img)
+        torch.manual_seed(1)
+        (out * torch.rand_like(out)).sum().backward()
+        torch.cuda.synchronize()
+        outs.append((out.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    # layers 5-10 (above both fused convs) see the same launches: bit-identical.  Below, the BatchNorm-backward sums of
+    # layers 1 and 3 come from another persistent grid (fp32 summation order) and dy is re-rounded to bf16 from there on.
+    same = 0
+    for k in outs[0][1]:
+        a, b = outs[0][1][k].double(), outs[1][1][k].double()
+        same += int(torch.equal(a, b))
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, k
+        else:
+            assert float((a - b).norm() / b.norm()) < 1e-2, k
+    assert same >= 24
+
+
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 def test_encoder_with_fused_bn_backward_matches_separate_pass(prec, monkeypatch):
     """Whole encoder, cnn.FUSE_BN_BWD on (default) vs off: forward identical; gradients equal up to the fp32 summation

@@ -222,9 +222,13 @@ __device__ __forceinline__ Packed4<T> epilogue4(const f32x4& acc, const f32x4& b
 template <typename T> struct Raw4;
 template <> struct Raw4<bf16> { unsigned lo, hi; };
 template <> struct Raw4<float> { f32x2 lo, hi; };
+// xact (bf16 only, may be null): receives the layer's ACTIVATION at the same (pixel, channels), round_T(max(z, 0)) and
+// zero outside the image - bit for bit what bn_relu_vec hands the forward conv - for the weight gradient formed in the
+// same kernel (conv3x3_igemm_p, VAR 3).
 template <typename T>
 __device__ __forceinline__ Packed4<T> epilogue4_bnbwd(const f32x4& acc, float okf, const Raw4<T>& y4,
-                                                      const f32x4 (&cf)[4], f32x2 (&s1)[2], f32x2 (&s2)[2]) {
+                                                      const f32x4 (&cf)[4], f32x2 (&s1)[2], f32x2 (&s2)[2],
+                                                      unsigned* xact = nullptr) {
     const f32x2 p[2] = {f32x2{acc[0], acc[1]}, f32x2{acc[2], acc[3]}};
     Packed4<T> out;
 #pragma unroll
@@ -246,6 +250,13 @@ __device__ __forceinline__ Packed4<T> epilogue4_bnbwd(const f32x4& acc, float ok
         const f32x2 sc = {cf[0][2 * h], cf[0][2 * h + 1]}, sh = {cf[1][2 * h], cf[1][2 * h + 1]},
                     mu = {cf[2][2 * h], cf[2][2 * h + 1]}, is = {cf[3][2 * h], cf[3][2 * h + 1]};
         const f32x2 z = __builtin_elementwise_fma(yv, sc, sh);
+        if constexpr (sizeof(T) == 2) {
+            if (xact) {
+                typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                const bf16x2_t t = {(bf16)(okf != 0.f ? fmaxf(z.x, 0.f) : 0.f), (bf16)(okf != 0.f ? fmaxf(z.y, 0.f) : 0.f)};
+                xact[h] = __builtin_bit_cast(unsigned, t);
+            }
+        }
         f32x2 dz = v * f32x2{okf, okf};
         dz.x = z.x > 0.f ? dz.x : 0.f;
         dz.y = z.y > 0.f ? dz.y : 0.f;

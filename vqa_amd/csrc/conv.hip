@@ -45,6 +45,11 @@ struct ConvArgs {
     const void* bn_y;
     const float* bn_coef;
     int rev;            // persistent kernels: walk the units back to front (unit_walk, common.h)
+    // BST + weight gradient (persistent bf16 kernels, VAR 3): the conv this call is the data gradient OF also gets its
+    // weight gradient here - x = relu(scale * bn_y + shift) at the tile's pixels (already loaded for the sums) against
+    // the 9 shifted views of the staged dy patch - as one partial slab per workgroup, [G][Cin][9][Cout] f32 in THIS
+    // call's channel names (= vqa_conv3x3_wgrad's [G][Cout][9][Cin] in the forward conv's).
+    float* wpart;
 };
 
 template <typename T, int CK> struct ConvCfg {
@@ -448,12 +453,27 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv3x3_igemm_til
 // partial sums stay in registers across tiles: ONE statistics row per workgroup.
 // (the BST form of the 32-channel kernel: held to three waves per SIMD - 168 registers, what its plain form has - it
 // spills 52 bytes per lane; at two waves per SIMD it does not, and the 114x114 32->32 data gradient is 4 % faster)
+// VAR 3 = BST + the weight gradient of the same conv (ConvArgs::wpart).  Both gradients of a conv read dy and the lower
+// layer's y; as two kernels each tensor crossed the fabric twice (418 MB each in block 1).  Here the tile's x is formed
+// in the BST epilogue from the y values it loads anyway, parked in LDS as [pixel][channel] (the transposing reads want
+// the reduction axis - pixels - as rows), and dW[co][8 - t][ci] += sum_pixels dy_patch[pixel + t][co] * x[pixel][ci]
+// over the 9 rotated taps t of the patch that the data gradient staged.
+//   <16, 1>: one 16x16 tile per tap; the 4 waves split the pixels (each reduces the 64 pixels whose x it wrote itself:
+//            no barrier), 36 accumulator registers, combined through LDS after the last tile
+//   <32, 2>: four 16x16 tiles per tap, one (co fragment, ci fragment) role per wave over all 256 pixels (one more
+//            barrier per tile: the x of the other waves)
 template <typename T, int CK, int NBF, int VAR>
 #ifndef VQA_BST_WAVES
 #define VQA_BST_WAVES 2
 #endif
-__global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) void conv3x3_igemm_p(ConvArgs a) {
-    constexpr bool XF = VAR == 1, BST = VAR == 2;
+#ifndef VQA_DW_WAVES
+#define VQA_DW_WAVES 3
+#endif
+__global__ __launch_bounds__(256, (VAR >= 2 && NBF == 2) ? VQA_BST_WAVES : ((VAR == 3 && NBF == 1) ? VQA_DW_WAVES : 1)) void conv3x3_igemm_p(ConvArgs a) {
+    constexpr bool XF = VAR == 1, BST = VAR >= 2, WG = VAR == 3;
+    static_assert(!WG || (sizeof(T) == 2 && ((CK == 16 && NBF == 1) || (CK == 32 && NBF == 2))), "weight-gradient forms");
+    constexpr bool WG_PSPLIT = WG && CK == 16;                  // waves split the pixels (else: the tiles)
+    constexpr int XSTR = NBF == 1 ? 32 : NBF * 32 + 32;         // LDS bytes per x pixel (32 * odd: dy_stride)
     using Cfg = ConvCfg<T, CK>;
     constexpr int VEC = Cfg::VEC, KC = Cfg::KC, KP = Cfg::KP, NS = Cfg::NS, PXB = Cfg::PXB, WROWB = Cfg::WROWB,
                   VPP = Cfg::VPP;
@@ -464,6 +484,7 @@ __global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) vo
     unsigned char* wl = smem + (a.R + 2) * PROWB;
     float* biasl = reinterpret_cast<float*>(wl + NB * WROWB);   // [NB]
     float* coefl = biasl + NB;                                  // XF: [2][CK] input scale / shift
+    unsigned char* xt = reinterpret_cast<unsigned char*>(coefl + 4 * NB);   // WG: [256][XSTR] activations of the tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -524,6 +545,22 @@ __global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) vo
     for (int n = 0; n < NBF; ++n)
 #pragma unroll
         for (int h = 0; h < 2; ++h) s1[n][h] = s2[n][h] = f32x2{0.f, 0.f};
+
+    // ---- WG: this wave's tiles of the weight gradient and the (tile-independent) LDS offsets of its k rows.
+    // k -> pixel map of a 32-pixel step as in conv3x3_wgrad: lane 16q + 4rq + p addresses pixel ks + 4q + rq (and + 16)
+    constexpr int WSTEPS = WG_PSPLIT ? 2 : 8;                   // 32-pixel steps per wave and tile
+    const int wcf = WG_PSPLIT ? 0 : (wave & 1), wnf = WG_PSPLIT ? 0 : (wave >> 1);   // role: dy / x channel fragment
+    f32x4 wacc[WG ? 9 : 1];
+    int* wptab = reinterpret_cast<int*>(xt + 256 * XSTR);       // [256] patch byte offset of tile pixel m
+    if constexpr (WG) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const int mm = tid < MT ? tid : 0;                  // x is zero beyond the tile: any finite dy
+            const int pr = fastdiv(mm, a.CW, a.inv_cw);
+            wptab[tid] = pr * PROWB + (mm - pr * a.CW) * PXB;   // (read behind the tile loop's first barrier)
+        }
+    }
 
     // ---- staging.  Out-of-image vectors are fetched at the buffer's size, which the hardware answers with zeros (the
     // zero padding costs one select per vector: no clamped address, no mask at the LDS write, no branch); the next
@@ -639,8 +676,43 @@ __global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) vo
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
                     const float okf = yoff[f][n] != ybytes ? 1.f : 0.f;
-                    const Packed4<T> o = epilogue4_bnbwd<T>(acc[f][n], okf, yv[f][n], cf, s1[n], s2[n]);
+                    unsigned xa[2];
+                    const Packed4<T> o = epilogue4_bnbwd<T>(acc[f][n], okf, yv[f][n], cf, s1[n], s2[n], WG ? xa : nullptr);
                     buffer_store_packed4<T>(ybuf, yoff[f][n], o);
+                    if constexpr (WG)
+                        *reinterpret_cast<uint2*>(xt + ((wave * 4 + f) * 16 + r) * XSTR + (n * 16 + q * 4) * 2) =
+                            make_uint2(xa[0], xa[1]);
+                }
+            }
+            if constexpr (WG) {
+                if constexpr (WG_PSPLIT) asm volatile("" ::: "memory");   // own rows only: LDS runs a wave's ops in order
+                else __syncthreads();
+                typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4;
+                // (recomputed per tile from an opaque copy of the thread id: held across the loop these three values
+                // were what pushed the <16, 1> form over its 168 registers - and the spill reload sat between the y
+                // loads and the next tile's prefetch, which then waited for both)
+                int tl = tid;
+                asm volatile("" : "+v"(tl));
+                const int lr = tl & 15, lq = (tl >> 4) & 3;
+                const int wm0 = (WG_PSPLIT ? (tl >> 6) * 64 : 0) + lq * 4 + (lr >> 2);     // this lane's k row of step 0
+                const int wpc = (wcf * 16 + 4 * (lr & 3)) * 2;                             // its channel bytes in a patch pixel
+                const unsigned char* wxb = xt + wm0 * XSTR + (wnf * 16 + 4 * (lr & 3)) * 2;   // its address in the x tile
+#pragma unroll
+                for (int st = 0; st < WSTEPS; ++st) {
+                    if ((WG_PSPLIT ? wave * 64 : 0) + st * 32 >= MT) break;          // (uniform per wave)
+                    const bf16x4 xl = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(wxb + st * 32 * XSTR));
+                    const bf16x4 xh = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(wxb + (st * 32 + 16) * XSTR));
+                    const bf16x8 fx = {xl[0], xl[1], xl[2], xl[3], xh[0], xh[1], xh[2], xh[3]};
+                    const unsigned char* d0 = patch + wptab[wm0 + st * 32] + wpc;
+                    const unsigned char* d1 = patch + wptab[wm0 + st * 32 + 16] + wpc;
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) {
+                        const int toff = (tp / 3) * PROWB + (tp % 3) * PXB;
+                        const bf16x4 dl = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(d0 + toff));
+                        const bf16x4 dh = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(d1 + toff));
+                        const bf16x8 fd = {dl[0], dl[1], dl[2], dl[3], dh[0], dh[1], dh[2], dh[3]};
+                        Mma<T>::mma(wacc[tp], __builtin_bit_cast(uint4, fd), __builtin_bit_cast(uint4, fx));
+                    }
                 }
             }
         } else {
@@ -674,6 +746,33 @@ __global__ __launch_bounds__(256, (VAR == 2 && NBF == 2) ? VQA_BST_WAVES : 1) vo
             a.stats[((long)blockIdx.x * a.Cout + co0) * 2 + tid] = tt;
         }
     }
+    if constexpr (WG) {
+        // D rows (4q + e) = dy channel, D cols (r) = x channel; tap t of the rotated patch is tap 8 - t of the conv
+        float* slab = a.wpart + (long)blockIdx.x * a.Cin * 9 * a.Cout;
+        if constexpr (WG_PSPLIT) {
+            __syncthreads();                                    // (the statistics rows above)
+            float* red = reinterpret_cast<float*>(smem);        // [4 waves][9][64 lanes][4]
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) *reinterpret_cast<f32x4*>(red + ((wave * 9 + tp) * 64 + lane) * 4) = wacc[tp];
+            __syncthreads();
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {                    // thread = (lane tid / 4, element tid % 4) of tile tp
+                const int i = tp * 256 + tid;
+                const float v = ((red[i] + red[2304 + i]) + red[2 * 2304 + i]) + red[3 * 2304 + i];
+                const int l = tid >> 2, e = tid & 3;
+                const int cd = (l >> 4) * 4 + e, cx = co0 + (l & 15);
+                slab[(cd * 9 + (8 - tp)) * a.Cout + cx] = v;
+            }
+        } else {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cd = wcf * 16 + q * 4 + e, cx = co0 + wnf * 16 + r;
+                    slab[(cd * 9 + (8 - tp)) * a.Cout + cx] = wacc[tp][e];
+                }
+        }
+    }
 }
 
 // LDS of either variant (the persistent one adds the resident bias row)
@@ -695,14 +794,27 @@ size_t igemm_lds(const ConvArgs& a) {
 //   multi chunk:              one workgroup per (tile, image), G = tiles * B
 template <typename T, int CK, int NBF>
 int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
-    const size_t lds = igemm_lds<T, CK, NBF>(a);
+    size_t lds = igemm_lds<T, CK, NBF>(a);
     const int total = a.tiles_x * a.tiles_y * a.B, zb = a.Cout / (NBF * 16);
-    if (lds > 160 * 1024) return plan_only ? -1 : VQA_ERR_ARG;
     const bool persistent = a.Cin == CK;
-    const int var = a.in_scale ? 1 : (a.bn_y ? 2 : 0);
-    auto kp = var == 1 ? conv3x3_igemm_p<T, CK, NBF, 1> : (var == 2 ? conv3x3_igemm_p<T, CK, NBF, 2> : conv3x3_igemm_p<T, CK, NBF, 0>);
+    const int var = a.in_scale ? 1 : (a.bn_y ? (a.wpart ? 3 : 2) : 0);
+    auto kp = var == 1 ? conv3x3_igemm_p<T, CK, NBF, 1> : (var >= 2 ? conv3x3_igemm_p<T, CK, NBF, 2> : conv3x3_igemm_p<T, CK, NBF, 0>);
+    if (var == 3) {
+        // the forms the kernel has (bf16, all of the conv's channels in one workgroup), + the x tile; the <16, 1>
+        // form's combine buffer of the last tile is the floor
+        constexpr bool have = sizeof(T) == 2 && ((CK == 16 && NBF == 1) || (CK == 32 && NBF == 2));
+        if constexpr (have) {
+            if (!persistent || zb != 1) return plan_only ? -1 : VQA_ERR_ARG;
+            kp = conv3x3_igemm_p<T, CK, NBF, 3>;
+            lds += 256 * (NBF == 1 ? 32 : NBF * 32 + 32) + 1024;
+            if (CK == 16 && lds < 4 * 9 * 1024) lds = 4 * 9 * 1024;
+        } else {
+            return plan_only ? -1 : VQA_ERR_ARG;
+        }
+    }
+    if (lds > 160 * 1024) return plan_only ? -1 : VQA_ERR_ARG;
     auto kt = var == 1 ? conv3x3_igemm_tile<T, CK, NBF, 1>
-                       : (var == 2 ? conv3x3_igemm_tile<T, CK, NBF, 2> : conv3x3_igemm_tile<T, CK, NBF, 0>);
+                       : (var >= 2 ? conv3x3_igemm_tile<T, CK, NBF, 2> : conv3x3_igemm_tile<T, CK, NBF, 0>);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(persistent ? (const void*)kp : (const void*)kt,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1189,8 +1301,10 @@ __global__ void nchw_to_nhwc(const TI* in, T* out, int B, int C, int H, int W, i
 static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* wpacked, void* y, const float* bias,
                           float* stats, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW,
                           int G, bool plan_only, int relu = 0, const float* in_scale = nullptr,
-                          const float* in_shift = nullptr, const void* bn_y = nullptr, const float* bn_coef = nullptr) {
+                          const float* in_shift = nullptr, const void* bn_y = nullptr, const float* bn_coef = nullptr,
+                          float* wpart = nullptr) {
     const int bad = plan_only ? -1 : VQA_ERR_ARG;
+    if (wpart && (!bn_y || pad != 2)) return bad;   // (pad 2 = the data gradient of a pad-0 conv: x has no zero border)
     if ((in_scale != nullptr) != (in_shift != nullptr) || (in_scale && pad != 0)) return bad;
     if ((bn_y != nullptr) != (bn_coef != nullptr) || (bn_y && (in_scale || relu || bias || (!plan_only && !stats))))
         return bad;
@@ -1203,7 +1317,7 @@ static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* w
     const int tx_ = (OW + CW - 1) / CW, ty_ = (OH + R - 1) / R;
     ConvArgs a{x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
                1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), relu, in_scale, in_shift, bn_y, bn_coef,
-               vqa_walk_rev(in_scale ? 2 : (bn_y ? 4 : 1))};
+               vqa_walk_rev(in_scale ? 2 : (bn_y ? 4 : 1)), wpart};
     if (dtype == VQA_BF16) {
         if (Cin % 32 == 0) return dispatch_nb<bf16, 32>(s, a, G, plan_only);
         if (Cin == 16) return dispatch_nb<bf16, 16>(s, a, G, plan_only);
@@ -1232,10 +1346,21 @@ extern "C" int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int O
     // the variants are different instantiations with their own register counts, hence their own resident grids
     static const float dummy = 0.f;
     const float* xf = variant == 1 ? &dummy : nullptr;
-    const float* bst = variant == 2 ? &dummy : nullptr;
-    if (variant < 0 || variant > 2) return -1;
+    const float* bst = variant >= 2 ? &dummy : nullptr;
+    if (variant < 0 || variant > 3) return -1;
     return conv_fwd_entry(nullptr, dtype, nullptr, nullptr, nullptr, nullptr, nullptr, B, IH, IW, Cin, OH, OW, Cout,
-                          pad, R, CW, 0, true, 0, xf, xf, bst, bst);
+                          pad, R, CW, 0, true, 0, xf, xf, bst, bst, variant == 3 ? const_cast<float*>(&dummy) : nullptr);
+}
+
+// The data gradient of a pad-0 conv (vqa_conv3x3_fwd with bn_y / bn_coef, pad = 2) that ALSO leaves that conv's weight
+// gradient behind: wpart [G][Cin][9][Cout] f32 partial slabs (Cin = dy's channels = the conv's output channels), to
+// be summed by vqa_conv3x3_wgrad_reduce_all (desc: G, Cin, Cout, real input channels).  G from vqa_conv3x3_plan variant 3.
+extern "C" int vqa_conv3x3_dgrad_wgrad(void* stream, int dtype, const void* dy, const void* wpacked, void* dx,
+                                       float* stats, float* wpart, int B, int IH, int IW, int Cin, int OH, int OW,
+                                       int Cout, int pad, int R, int CW, int G, const void* bn_y, const float* bn_coef) {
+    if (!wpart) return VQA_ERR_ARG;
+    return conv_fwd_entry(static_cast<hipStream_t>(stream), dtype, dy, wpacked, dx, nullptr, stats, B, IH, IW, Cin, OH,
+                          OW, Cout, pad, R, CW, G, false, 0, nullptr, nullptr, bn_y, bn_coef, wpart);
 }
 
 extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const void* dy, float* part, float* dw,

@@ -325,6 +325,9 @@ def test_encoder_with_fused_bn_forward_is_bit_identical(prec, padding, pooling, 
     from vqa_amd import cnn as M, synth
     sd = {k[4:]: v for k, v in synth.state_dict(42, 64, 50, 30).items() if k.startswith('cnn.')}
     img = synth.images(9, B, size).cuda()
+    # (vqa_conv3x3_dgrad_wgrad exists only for the fused-forward form and sums its weight-gradient slabs over another
+    # grid: off here, so that both runs issue the same weight-gradient launches; it has its own tests below)
+    monkeypatch.setattr(M, 'FUSE_DGRAD_WGRAD', 0)
     outs = []
     for fuse in (True, False):
         monkeypatch.setattr(M, 'FUSE_BN_FWD', fuse)

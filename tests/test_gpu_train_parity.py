@@ -425,6 +425,35 @@ def test_gradient_accumulation_with_side_streams(prec, tmp_path, monkeypatch):
     assert torch.equal(out[0][3], out[1][3]) and torch.equal(out[0][3], out[0][1]['linear_inside_relu_last.weight_v'])
 
 
+@pytest.mark.parametrize('knob', ['HEAD_DQ_SIDE', 'HEAD_WN_EARLY'])
+def test_head_stream_knobs_are_bit_identical(knob, tmp_path, monkeypatch):
+    """The two measured-and-not-kept placements of head work (vqa_model.HEAD_DQ_SIDE: the question gradient leads the
+    parameter-gradient work on the weight-gradient stream; HEAD_WN_EARLY: the weight norms issued at the start of the
+    forward on that stream) change streams, not launches: logits and every gradient bit for bit, two steps in a row
+    (the second starts while the first one's side-stream work may still be running)."""
+    import vqa_model
+    from vqa_amd import vqa_model as VM
+    c = load_case('h64_p5_max')
+    img, q, t = c['images'].cuda(), c['questions'].cuda(), c['targets'].cuda()
+    crit = vqa_model.SoftScoreBCELoss()
+    out = []
+    for on in (True, False):
+        monkeypatch.setattr(VM, knob, on)
+        m = build_model(c, tmp_path, 'bf16').cuda().train()
+        res = []
+        for rep in range(2):
+            m.zero_grad(set_to_none=True)
+            logits = m(img, q)
+            crit(logits, t).backward()
+            torch.cuda.synchronize()
+            res.append((logits.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+        out.append(res)
+    for (la, ga), (lb, gb) in zip(*out):
+        assert torch.equal(la, lb)
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+
+
 def test_soft_accuracy_on_nan_and_inf_rows():
     """A diverged model reaching evaluate(): rows of NaN / -inf logits.  torch.argmax returns a valid index (the first
     NaN, else the first maximum) and the reference's loop carries on (vqa_model.py:127-130); so must the kernels -

@@ -93,6 +93,18 @@ HEAD_LAYERS = ['linear_inside_relu_attention', 'linear_after_relu_attention', 'l
 # 4 alternations of 60 steps: 4.169 vs 4.139 ms/step) - the two event hops between hardware queues cost the chain more
 # than three 6 us kernels do.
 HEAD_DQ_STREAM = os.environ.get('VQA_HEAD_DQ_STREAM', '0') != '0'
+# VQA_HEAD_DQ_SIDE=1: those three launches lead the head's parameter-gradient work on the WEIGHT-GRADIENT stream (which
+# that work is ordered behind the chain by one event anyway) and the question encoder's stream waits for them: the chain
+# to the CNN's backward neither runs them nor records anything more.  Off: same-box A/B, 2 alternations of 60 steps,
+# 4.048 / 4.075 against 4.018 / 4.098 ms/step - 29 us of kernels less on the chain and nothing gained (what the chain
+# sheds still runs beside it on the same CUs).
+HEAD_DQ_SIDE = os.environ.get('VQA_HEAD_DQ_SIDE', '0') != '0'
+# VQA_HEAD_WN_EARLY=1: the six weight norms of the head (W = g v / ||v||: two launches, ~30 us, parameters only) are
+# issued at the start of forward() on the weight-gradient stream, which is idle during the forward pass, instead of on
+# the chain between the CNN's forward and backward.  Off: measured SLOWER in the same A/B (4.109 / 4.126 ms/step) - the
+# 28 MB of bf16 matrices are written 1.2 ms before the head's GEMMs read them, and the CNN's forward evicts them from
+# the Infinity Cache in between (round 1 saw the same with them on the question encoder's stream).
+HEAD_WN_EARLY = os.environ.get('VQA_HEAD_WN_EARLY', '0') != '0'
 # Head parameter gradients on the weight-gradient stream (see _HeadFunction.backward); VQA_HEAD_WGRAD_STREAM=0: inline
 HEAD_WGRAD_STREAM = os.environ.get('VQA_HEAD_WGRAD_STREAM', '1') != '0'
 
@@ -104,7 +116,7 @@ class _HeadFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, v, q, dtype, masks, target, g_att, v_att, b_att, g_s, v_s, g_img, v_img, b_img, g_q, v_q, b_q,
-                g_last, v_last, b_last, g_fc, v_fc, act=1):
+                g_last, v_last, b_last, g_fc, v_fc, act=1, pre_wn=None):
         # act: 1 = nn.ReLU, 3 = nn.SELU (vqa_model.py:54).  masks = (mask1, mask2, add1, add2): the two dropout sites
         # compute x * mask + add (nn.Dropout: add None; nn.AlphaDropout: see _alpha_dropout_noise)
         B, K, D = v.shape
@@ -114,8 +126,10 @@ class _HeadFunction(torch.autograd.Function):
         q = q.contiguous()
         mask1, mask2, add1, add2 = masks
         # all six weight-normed layers: W = g * v / ||v||_F (and W^T for the backward) in two launches
-        wn, ss = ops.weight_norm_fwd_all([(v_att, g_att, True), (v_s, g_s, False), (v_img, g_img, True),
-                                          (v_q, g_q, True), (v_last, g_last, True), (v_fc, g_fc, True)], dtype)
+        # (pre_wn: the same, issued earlier on another stream by VQA.forward - HEAD_WN_EARLY)
+        wn, ss = pre_wn if pre_wn is not None else ops.weight_norm_fwd_all(
+            [(v_att, g_att, True), (v_s, g_s, False), (v_img, g_img, True), (v_q, g_q, True), (v_last, g_last, True),
+             (v_fc, g_fc, True)], dtype)
         (W_att, W_att_T), (w_s, _), (W_img, W_img_T), (W_q, W_q_T), (W_last, W_last_T), (W_fc, W_fc_T) = wn
 
         # the encoders hand over the MFMA-dtype copies they already hold (the last block's bf16 output, the recurrence's
@@ -194,22 +208,30 @@ class _HeadFunction(torch.autograd.Function):
         L.call('vqa_attn_bwd', L.dt(a), a, w_s, v, p, dvhat, B, K, H, D, dv, dpre_a, dws_part, act)
         ops.gemm(dpre_a, W_att_T[:D], out=dv, accumulate=True)                   # += dpre_a @ W_v
         # dv is what the image encoder's backward - the critical chain - waits for.  The question encoder's gradient
-        # (three more launches) is formed on the stream its backward will run on (ctx.q_stream: the question encoder's
-        # side stream, where the recurrence's BPTT ends 1.2 ms before the CNN's backward does)
-        qs = ctx.q_stream if (HEAD_DQ_STREAM and ctx.q_stream is not None) else None
+        # (three more launches) only feeds the recurrence's BPTT, which ends long before the CNN's backward does: it
+        # leads the parameter-gradient work on the weight-gradient stream (HEAD_DQ_SIDE), or is formed on the stream the
+        # BPTT will run on (HEAD_DQ_STREAM; ctx.q_stream), or stays on this chain
+        def question_grad():
+            dq = ops.gemm(dpq, W_q_T)                                            # [B,H]
+            dqa, dqa_t = new(B, H, dt=torch.float32), new(B, H)
+            L.call('vqa_group_sum', L.dt(dpre_a), dpre_a, B, K, H, dqa, dqa_t)
+            ops.gemm(dqa_t, W_att_T[D:], out=dq, accumulate=True)                # += dqa @ W_q-part
+            return dq, dqa, dqa_t
+
         main = torch.cuda.current_stream()
+        dq_side = HEAD_DQ_SIDE and HEAD_WGRAD_STREAM
+        qs = ctx.q_stream if (HEAD_DQ_STREAM and not dq_side and ctx.q_stream is not None) else None
         if qs is not None and qs != main:
             qs.wait_event(main.record_event())
             for t in (dpq, dpre_a, W_q_T, W_att_T):
                 t.record_stream(qs)
         else:
             qs = None
-        with torch.cuda.stream(qs if qs is not None else main):
-            dq = ops.gemm(dpq, W_q_T)                                            # [B,H]
-            dqa, dqa_t = new(B, H, dt=torch.float32), new(B, H)
-            L.call('vqa_group_sum', L.dt(dpre_a), dpre_a, B, K, H, dqa, dqa_t)
-            ops.gemm(dqa_t, W_att_T[D:], out=dq, accumulate=True)                # += dqa @ W_q-part
-        dq_done = qs.record_event() if qs is not None else None
+        dq_done = None
+        if not dq_side:
+            with torch.cuda.stream(qs if qs is not None else main):
+                dq, dqa, dqa_t = question_grad()
+            dq_done = qs.record_event() if qs is not None else None
 
         # ---- parameter gradients: nothing downstream in this backward needs them, so they run on the weight-gradient
         # stream beside the encoders' backward (ops.defer_join: joined before backward() returns / before a bucket
@@ -253,7 +275,20 @@ class _HeadFunction(torch.autograd.Function):
                                  for h in (getattr(p, '_post_accumulate_grad_hooks', None) or {}).values())
                              for p in head_params)
             with torch.cuda.stream(side):
+                if dq_side:
+                    dq, dqa, dqa_t = question_grad()
+                    dq_ev = side.record_event()
                 wn, db_att, db_img, db_q, db_last = weights()
+            if dq_side:
+                # the recurrence's BPTT runs on the stream its forward ran on (autograd), else on this one
+                bptt = ctx.q_stream if ctx.q_stream is not None else cur
+                bptt.wait_event(dq_ev)
+                for t in (dq, dqa, dqa_t):
+                    t.record_stream(cur)                # (made on the side stream; dq travels through autograd from here)
+                    if bptt != cur:
+                        t.record_stream(bptt)
+                for t in (W_q_T, W_att_T):
+                    t.record_stream(side)
             for t in (dl_t, m_t, dpre_last, m0, dpv, vhat_t, dpq, q_t, dws_part, dqa, dpre_a, v_t, dqa_t, ss):
                 t.record_stream(side)                                            # (freed on this stream, read on that)
             if adopt_only:
@@ -271,7 +306,7 @@ class _HeadFunction(torch.autograd.Function):
                 t.record_stream(main)           # (made on the question stream; dq travels through autograd from here)
         (dg_att, dv_att), (dg_s, dv_s), (dg_img, dv_img), (dg_q, dv_q), (dg_last, dv_last), (dg_fc, dv_fc) = wn
         return (dv.reshape(B, K, D), dq, None, None, None, dg_att, dv_att, db_att, dg_s, dv_s, dg_img, dv_img, db_img,
-                dg_q, dv_q, db_q, dg_last, dv_last, db_last, dg_fc, dv_fc, None)
+                dg_q, dv_q, db_q, dg_last, dv_last, db_last, dg_fc, dv_fc, None, None)
 
 
 class VQA(nn.Module):
@@ -342,8 +377,11 @@ class VQA(nn.Module):
         # The question encoder (28 small latency-bound launches per direction) is independent of the image
         # encoder: it runs on a side HIP stream, under the CNN kernels.  Autograd replays each backward on its
         # forward's stream, so the GRU's BPTT overlaps the CNN backward the same way.
+        pre_wn = None
         if SIDE_STREAM:
             cur = torch.cuda.current_stream()
+            if HEAD_WN_EARLY and cnn.WGRAD_STREAM:
+                pre_wn = self._weight_norms_early(cur, images_batch.device)
             # (data parallelism, optim.DP_FOLD_STREAMS: the Trainer marks the model and the question encoder shares the
             # weight-gradient stream - two compute streams + RCCL's own)
             side = (cnn._wgrad_stream if getattr(self, '_dp_fold_streams', False) else _side_stream)(images_batch.device)
@@ -357,9 +395,30 @@ class VQA(nn.Module):
         else:
             images_representation = self.cnn(images_batch, mirror)
             questions_representation = self.gru(questions_batch)
-        return self.head(images_representation, questions_representation, dropout_noise, _target)
+        if pre_wn is not None:
+            cur.wait_event(pre_wn[2])
+        return self.head(images_representation, questions_representation, dropout_noise, _target, _pre_wn=pre_wn)
 
-    def head(self, images_representation, questions_representation, dropout_noise=None, target=None):
+    def _weight_norms_early(self, cur, dev):
+        """The head's six weight norms (parameters only) on the weight-gradient stream, which is idle during the forward
+        pass: -> (views, sumsq, event).  Everything it allocates is used on `cur` later (record_stream)."""
+        dtype = torch.bfloat16 if self.precision == 'bf16' else torch.float32
+        a, s, i, qq, l, f = (getattr(self, n) for n in HEAD_LAYERS)
+        side = cnn._wgrad_stream(dev)
+        side.wait_event(cur.record_event())         # (the parameters' last writer - the optimizer - ran on `cur`)
+        with torch.cuda.stream(side), torch.no_grad():
+            wn, ss = ops.weight_norm_fwd_all([(a.weight_v, a.weight_g, True), (s.weight_v, s.weight_g, False),
+                                              (i.weight_v, i.weight_g, True), (qq.weight_v, qq.weight_g, True),
+                                              (l.weight_v, l.weight_g, True), (f.weight_v, f.weight_g, True)], dtype)
+            ev = side.record_event()
+        for w, wt in wn:
+            for t in (w, wt):
+                if t is not None:
+                    t.record_stream(cur)
+        ss.record_stream(cur)
+        return wn, ss, ev
+
+    def head(self, images_representation, questions_representation, dropout_noise=None, target=None, _pre_wn=None):
         """Attention + fusion + classifier (vqa_model.py:83-103) on given encoder outputs v [B,k,256], q [B,H] (fp32):
         the second half of forward(), callable on its own (parity tests feed it the oracle's encoder outputs).
         With `target` it returns (logits, loss) - see forward_loss()."""
@@ -381,7 +440,7 @@ class VQA(nn.Module):
         logits, loss = _HeadFunction.apply(images_representation, questions_representation, dtype, masks, target,
                                    a.weight_g, a.weight_v, a.bias, s.weight_g, s.weight_v, i.weight_g, i.weight_v,
                                    i.bias, qq.weight_g, qq.weight_v, qq.bias, l.weight_g, l.weight_v, l.bias,
-                                   f.weight_g, f.weight_v, act)
+                                   f.weight_g, f.weight_v, act, None if _pre_wn is None else _pre_wn[:2])
         return logits if target is None else (logits, loss)
 
 

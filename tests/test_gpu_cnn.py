@@ -20,7 +20,11 @@ def _nhwc(x, dtype):
 @pytest.mark.parametrize('B,cin,cout,H,W,pad', [(2, 16, 16, 20, 20, 0), (3, 16, 32, 13, 17, 2), (2, 32, 64, 9, 9, 2),
                                                 (1, 64, 64, 30, 30, 0), (2, 128, 256, 14, 14, 0),
                                                 (2, 256, 256, 12, 12, 0), (1, 16, 16, 70, 226, 2), (2, 16, 64, 10, 11, 2),
-                                                (2, 32, 16, 9, 12, 0), (3, 32, 32, 40, 23, 2)])
+                                                (2, 32, 16, 9, 12, 0), (3, 32, 32, 40, 23, 2),
+                                                # two images per tile (ConvArgs::seam): even B, pad 0, multi-chunk, a map
+                                                # small enough for a pair; and the same maps with an odd B (unpaired)
+                                                (4, 64, 64, 10, 10, 0), (6, 128, 64, 12, 9, 0), (3, 64, 64, 10, 10, 0),
+                                                (2, 64, 32, 5, 4, 0)])
 def test_conv_fwd_dgrad_wgrad_exact(prec, B, cin, cout, H, W, pad):
     """Small-integer data: every product and sum is exact in bf16/f32, so results must match bit for bit."""
     from vqa_amd import cnn as C
@@ -54,7 +58,8 @@ def test_conv_fwd_dgrad_wgrad_exact(prec, B, cin, cout, H, W, pad):
 
 
 @pytest.mark.parametrize('B,cin,cout,H,W,pad', [(1, 64, 128, 19, 21, 0), (2, 128, 64, 33, 18, 2), (3, 256, 256, 12, 12, 0),
-                                                (2, 64, 32, 31, 17, 2), (1, 96, 64, 45, 45, 0)])
+                                                (2, 64, 32, 31, 17, 2), (1, 96, 64, 45, 45, 0),
+                                                (4, 256, 256, 12, 12, 0), (2, 64, 128, 8, 11, 0)])   # (paired images)
 def test_multi_chunk_statistics_are_the_sums_of_the_stored_outputs(B, cin, cout, H, W, pad):
     """bf16 multi-chunk conv (Cin > 32): the BatchNorm statistics are formed by MFMA from the transposed bf16 tile on
     its way out (conv.hip: F^T F and 1^T F over the tile's pixels).  Random data, tiles that hang over the image's

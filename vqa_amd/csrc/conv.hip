@@ -50,6 +50,11 @@ struct ConvArgs {
     // the 9 shifted views of the staged dy patch - as one partial slab per workgroup, [G][Cin][9][Cout] f32 in THIS
     // call's channel names (= vqa_conv3x3_wgrad's [G][Cout][9][Cin] in the forward conv's).
     float* wpart;
+    // Two images per tile (multi-chunk kernel, pad 0, one tile per image: the 10x10 maps fill 7 of a tile's 16 fragment
+    // slots): consecutive images are contiguous in NHWC, so a PAIR is one image of 2 IH rows whose valid convolution has
+    // 2 OH + 2 rows - `seam` = the real OH; output rows seam, seam + 1 straddle the two images and are dropped, rows from
+    // seam + 2 on are rows 0.. of the second image.  B, IH, OH in here are then those of the pairs.  0 = off.
+    int seam;
 };
 
 template <typename T, int CK> struct ConvCfg {
@@ -222,9 +227,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv3x3_igemm_til
         const int m = (f * 4 + wave) * 16 + r;
         int pc;
         int pr = fastdivmod(m < MT ? m : 0, a.CW, a.inv_cw, pc);
-        const bool ok = m < MT && (oy0 + pr < a.OH) && (ox0 + pc < a.OW);
+        bool ok = m < MT && (oy0 + pr < a.OH) && (ox0 + pc < a.OW);
         pbase[f] = __mul24(pr, PROWB) + __mul24(pc, PXB);
-        const int op = __mul24(b * a.OH + oy0 + pr, a.OW) + ox0 + pc;
+        int orow = b * a.OH + oy0 + pr;                                  // row of the [B * OH] x OW output
+        if (a.seam) {                                                       // (see ConvArgs::seam; oy0 = 0 there)
+            ok = ok && (unsigned)(pr - a.seam) >= 2u;
+            orow = __mul24(b, 2 * a.seam) + pr - (pr >= a.seam + 2 ? 2 : 0);
+        }
+        const int op = __mul24(orow, a.OW) + ox0 + pc;
         opix[f] = ok ? op : -1;
     }
 
@@ -1314,10 +1324,21 @@ static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* w
     // the kernels address x and y through 32-bit byte offsets (buffer resources)
     const int esz_ = dtype == VQA_BF16 ? 2 : 4;
     if ((double)B * IH * IW * Cin * esz_ >= 4294967040.0 || (double)B * OH * OW * Cout * esz_ >= 4294967040.0) return bad;
+    // two images per tile (ConvArgs::seam): the multi-chunk kernel's one-tile-per-image maps with room for a second
+    // image in the tile's 256 pixels and the patch's 384 - the 10x10 map of the last conv (100 of 256 pixels: 7 of 16
+    // fragment slots, and a 37 KB weight slab staged per chunk for them)
+    static const int pair_on = [] { const char* e = getenv("VQA_CONV_PAIR"); return e ? atoi(e) : 1; }();
+    int seam = 0;
+    const int ck_ = dtype == VQA_BF16 ? 32 : 16;
+    if (pair_on && pad == 0 && !bn_y && Cin > ck_ && R >= OH && CW >= OW && B % 2 == 0 && (2 * OH + 2) * CW <= 256 &&
+        (2 * IH) * (CW + 2) <= 384) {
+        seam = OH;
+        B /= 2; IH *= 2; OH = 2 * OH + 2; R = OH;
+    }
     const int tx_ = (OW + CW - 1) / CW, ty_ = (OH + R - 1) / R;
     ConvArgs a{x, wpacked, y, bias, stats, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
                1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), relu, in_scale, in_shift, bn_y, bn_coef,
-               vqa_walk_rev(in_scale ? 2 : (bn_y ? 4 : 1)), wpart};
+               vqa_walk_rev(in_scale ? 2 : (bn_y ? 4 : 1)), wpart, seam};
     if (dtype == VQA_BF16) {
         if (Cin % 32 == 0) return dispatch_nb<bf16, 32>(s, a, G, plan_only);
         if (Cin == 16) return dispatch_nb<bf16, 16>(s, a, G, plan_only);

@@ -11,9 +11,10 @@
  *     state, caches no stream or device, allocates nothing, and is re-entrant (autograd worker threads call it) - the
  *     one exception is vqa_soft_accuracy_sum_noalloc, which owns a static per-GPU scratch array (see there);
  *   - the caller owns every buffer (inputs, outputs, workspaces, saved-for-backward tensors), all device memory;
- *   - three speed-only switches are read from the environment once per process: VQA_PLAN_RESERVE,
- *     VQA_WALK_REV, VQA_NT_MIN_MB - they change the order in which a kernel walks its tiles, the size of a persistent
- *     grid or the cache policy of its accesses, never what is computed;
+ *   - speed-only switches are read from the environment once per process: VQA_PLAN_RESERVE,
+ *     VQA_WALK_REV, VQA_NT_MIN_MB, VQA_CONV_PAIR, VQA_WGRAD_COF4 - they change the order in which a kernel walks its
+ *     tiles, how many images share a tile, the size of a persistent grid or the cache policy of its accesses, never
+ *     what is computed (outputs identical; partial-sum rows may be cut differently: fp32 summation order);
  *   - dtype codes: 0 = f32, 1 = bf16, 2 = f16 (image input only).  "T" below = the activation / MFMA dtype;
  *   - activations are NHWC; matrices are row-major with an explicit leading dimension in elements.
  */
@@ -50,6 +51,10 @@ int vqa_conv_pack_all(void* stream, int dtype, int n, const void* const* w, void
  * multi-chunk kernel (Cin larger than one channel chunk: 32 for bf16, 16 for f32) further needs x < 2 GiB, Cin <= 256,
  * IH * IW and B * OH below 2^22 (signed 24-bit index products, float quotients) and `bias` 16-byte aligned; the BatchNorm statistics of a bf16
  * call are the sums over the ROUNDED outputs as stored (formed by MFMA from the tile on its way out).  Status 1 otherwise.
+ * Two images per tile: a multi-chunk call with pad 0 whose map is one tile (R >= OH, CW >= OW), B even,
+ * (2 OH + 2) * CW <= 256 and 2 IH * (CW + 2) <= 384 treats each PAIR of consecutive images as one image of 2 IH rows and
+ * drops the two output rows that straddle them (the 10x10 map of cnn.py:40 fills 7 of a tile's 16 fragment slots alone);
+ * vqa_conv3x3_plan() then returns G = B / 2 statistics rows.  Same outputs bit for bit; VQA_CONV_PAIR=0 turns it off.
  * in_scale / in_shift ([Cin] f32, both or neither; pad must be 0): x is the RAW output of the previous conv and the
  * input is relu(in_scale * x + in_shift) - that layer's nn.BatchNorm2d + nn.ReLU (cnn.py:23-24, ...), applied while
  * the input tile is staged, so the normalised activation is never written (bit-identical to vqa_bn_act_pool_fwd

@@ -99,3 +99,23 @@ def test_zero_fill(nwords, offset):
     assert buf[:offset].eq(7).all() and buf[offset:offset + nwords].eq(0).all() and buf[offset + nwords:].eq(7).all()
     with pytest.raises(L.VqaHipError):
         L.call('vqa_zero', buf, 6)                                     # not a multiple of 4 bytes
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,N,pad,off', [(256, 1024, 0, 0), (3584, 3072, 0, 0), (1500, 304, 8, 0), (256, 301, 3, 0),
+                                         (700, 64, 0, 1), (3, 24, 0, 0), (1024, 8, 0, 0), (1025, 520, 16, 0)])
+def test_colsum(dtype, M, N, pad, off):
+    """vqa_colsum (bias gradients: column sums of a gradient matrix): the 16-byte-load forms (one launch with 16 row
+    lanes for M <= 1024, row slabs + combine above), and the scalar form that serves odd widths, odd row strides and
+    unaligned views.  Small-integer data: every sum is exact in f32."""
+    from vqa_amd import ops
+    torch.manual_seed(M + N)
+    full = torch.randint(-4, 5, (M, N + pad + off), device='cuda').to(dtype)
+    x = full[:, off:off + N]                       # row stride N + pad + off; off = 1: not 16-byte aligned
+    got = ops.colsum(x)
+    assert torch.equal(got, x.float().sum(0))
+    out = torch.full((N,), float('nan'), device='cuda')
+    assert ops.colsum(x, out=out) is out and torch.equal(out, got)
+    xr = (torch.randn(M, N, device='cuda') * 0.5).to(dtype)
+    want = xr.double().sum(0)
+    assert float((ops.colsum(xr).double() - want).abs().max()) <= 2e-6 * float(xr.float().abs().sum(0).max()) + 1e-6

@@ -146,7 +146,9 @@ def colsum(x, M=None, N=None, out=None):
     N = x.shape[1] if N is None else N
     if out is None:
         out = torch.empty(N, device=x.device, dtype=torch.float32)
-    slabs = max(1, min(64, M // 64))
+    # short matrices (the head's [B, H] gradients): one launch, 16 row lanes per block; tall ones (the recurrence's
+    # [T*B, 3H] gate gradients): up to 64 row slabs + the fixed-order combine
+    slabs = 1 if M <= 1024 else min(64, M // 64)
     scr = torch.empty(slabs, N, device=x.device, dtype=torch.float32) if slabs > 1 else None
     L.call('vqa_colsum', L.dt(x), x, M, N, x.stride(0), out, scr, slabs)
     return out

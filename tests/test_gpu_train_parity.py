@@ -200,6 +200,70 @@ def test_b32_train_step_vs_golden(prec, tmp_path):
     print(f'\n[b32 {prec}] logits {e_logits:.2e} loss {e_loss:.2e} ' + ' '.join(f'{k} {e:.2e}' for k, e in worst.items()))
 
 
+# What ONE flipped ReLU decision may add on top of "1.5 x the reference's own distance from fp64" (below).  Of the
+# attention layer's B * k * H = 819,200 units one has an fp64 pre-activation of 4.7e-9 (typical: 0.27).  Every fp32
+# perturbation decides it anew - scripts/fp64_anchor.py: the fp64 head fed with this path's encoder outputs, with the
+# imported reference's, with only v or only q swapped, flips it each time - and that one unit is worth 2.0e-3 on the
+# layer's bias gradient and 9.8e-4 on its weight_v gradient.  Torch's fp32 run happens to leave it on fp64's side (3.4e-5
+# from fp64), this path's puts it on the other (1.97e-3): a coin, not an accuracy gap - the two fp32 encoders sit 3.2e-6
+# and 4.0e-6 from the fp64 encoder output, and on IDENTICAL encoder outputs the head agrees with the oracle to 3e-6
+# (_check_train_step).  What that unit sends back through dv reaches the last conv's weight gradient (1.1e-4 against
+# 3.5e-5); below it both encoders' own decisions dominate and the factor alone holds.
+FP64_SLACK = dict(cnn=2e-4, attention=4e-3, rest=2e-5, weight_g=2e-5)
+
+
+def test_fp32_gradients_are_as_close_to_an_fp64_run_as_the_reference_is(tmp_path):
+    """The fp32 statement without a hand-picked tolerance ("what's weak" 2).  The B=32 bounds above are 1e-2
+    for the image encoder's gradients where the north_star says 1e-4, because the reference's OWN fp32 gradients are only
+    that reproducible: ReLU / arg-max decisions flip on 1e-7 forward differences.  Here the same algorithm is run once
+    more in fp64 (the oracle on the CPU, double precision end to end: the exact answer to fp32 accuracy) and every
+    gradient of the HIP fp32 path must be no further from it than 1.5 x the imported reference's fp32 gradient is, plus
+    a stated slack per group (FP64_SLACK: rounding level for the question encoder, the projections and the classifier;
+    one flipped unit for the attention layer) - per parameter tensor; logits and loss likewise (there this path is
+    closer to fp64 than the reference: its weight norm sums pairwise, torch's naively - DESIGN.md section 2)."""
+    import vqa_model
+    from oracle import vqa_oracle as O
+    c = load_case('h1024_p2_max_b32')
+    g = c['golden']
+    dt = torch.float64
+    p = {k: (v.to(dt).detach().clone().requires_grad_(O.is_param(k)) if v.is_floating_point() else v)
+         for k, v in c['sd'].items()}
+    lo64 = O.head_forward(p, O.cnn_forward(p, c['images'].to(dt), c['padding'], c['pooling'], True, None, None),
+                          O.gru_forward(p, c['questions']))
+    loss64 = O.bce_sum(lo64, c['targets'].to(dt))
+    names = [k for k in p if O.is_param(k)]
+    g64 = dict(zip(names, torch.autograd.grad(loss64, [p[k] for k in names])))
+    m = build_model(c, tmp_path, 'fp32').cuda().train()
+    logits = m(c['images'].cuda(), c['questions'].cuda())
+    loss = vqa_model.SoftScoreBCELoss()(logits, c['targets'].cuda())
+    loss.backward()
+    e_hip, e_ref = rel_err(logits.detach().cpu(), lo64.detach()), rel_err(g['logits'], lo64.detach())
+    assert e_hip <= 1.5 * e_ref + 2e-6, (e_hip, e_ref)
+    l64 = float(loss64.detach())
+    assert abs(float(loss.detach()) - l64) <= 1.5 * abs(float(g['loss']) - l64) + 2e-6 * abs(l64)
+    worst, bad = {}, []
+    for k, prm in m.named_parameters():
+        if _is_conv_bias(k):
+            continue                                # (identically zero behind a training-mode BatchNorm)
+        exact = g64[k].reshape(-1).numpy()
+        idx = sample_idx(exact.size)
+        hip = prm.grad.detach().reshape(-1).cpu().numpy()[idx]
+        if k.endswith('weight_g'):                  # a dot product with cancellation: against the scale of its terms
+            kv = k[:-1] + 'v'
+            scale = float(g64[kv].norm()) * float(c['sd'][kv].norm()) / abs(float(c['sd'][k]))
+            eh, er = abs(float(hip[0]) - float(exact[0])) / scale, abs(float(g[f'gsamp/{k}'][0]) - float(exact[0])) / scale
+        else:
+            eh, er = rel_err(hip, exact[idx]), rel_err(g[f'gsamp/{k}'], exact[idx])
+        grp = _group(k)
+        if eh / (er + 2e-5) > worst.get(grp, (0.0,))[0]:
+            worst[grp] = (eh / (er + 2e-5), eh, er, k)
+        if not eh <= 1.5 * er + FP64_SLACK[grp]:
+            bad.append((k, eh, er))
+    print(f'\n[fp64 anchor] logits hip {e_hip:.2e} ref {e_ref:.2e}; worst hip / ref per group: ' +
+          '; '.join(f'{grp} {w[1]:.2e} / {w[2]:.2e} ({w[3]})' for grp, w in worst.items()))
+    assert not bad, bad
+
+
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 def test_dropout_replayed_vs_golden(prec, tmp_path):
     """Dropout p = 0.0381 (vqa_model.py:55, :101, :103, :407-416): with the reference's two recorded keep-masks the HIP

@@ -45,7 +45,13 @@ def gemm_splits(M, N, K, dtype, trans=False):
     if not trans and dtype == torch.bfloat16 and -(-M // 32) * -(-N // 32) <= 256 and K <= 1024:
         return 1              # gemm.hip: 32x32 tiles with eight stages of loads in flight, no split-K pass
     if blocks >= 160:
-        return 2 if (K >= 3072 and blocks < 384) else 1
+        # 128x128 tiles (gemm.hip picks them from 160 tiles on): a grid that leaves a quarter of the CUs without a
+        # workgroup and a long reduction run faster as two K slices, two workgroups per CU (the recurrence's dW_hh)
+        big = -(-M // 128) * -(-N // 128)
+        if 160 <= big < 256 and K >= 2048:
+            return 2
+        # (NT: 3584 x 300 x 3072 is 35 us whole and 42 in two slices)
+        return 2 if (trans and K >= 3072 and blocks < 384) else 1
     return max(1, min(K // 384, 320 // blocks, 16))
 
 

@@ -25,6 +25,17 @@ if mode == 'sync':
         tr.step(*batch)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f'step {i:2d}: {dt * 1e3:8.3f} ms   reserved {torch.cuda.memory_reserved() / 2**30:.2f} GiB', flush=True)
+elif mode == 'events':   # no synchronize at all: host issue time and GPU time (events) of each of the first 40 steps
+    evs, hs = [], []
+    e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
+    for i in range(40):
+        t0 = time.perf_counter()
+        tr.step(*batch)
+        hs.append(time.perf_counter() - t0)
+        e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
+    torch.cuda.synchronize()
+    for i in range(1, 40):
+        print(f'step {i:2d}: gpu {evs[i].elapsed_time(evs[i + 1]):7.3f} ms   host issue (incl. run-ahead wait) {hs[i] * 1e3:7.3f} ms')
 else:       # the driver's shape: 5 warm-up steps, synchronize, then blocks of 5 steps timed without synchronizing inside
     for _ in range(5):
         tr.step(*batch)

@@ -616,15 +616,17 @@ WGRAD_RELEASE_AT = int(os.environ.get('VQA_WGRAD_RELEASE_AT', '3'))
 
 
 def _bwd_slices(B, nbytes):
-    """Batch slices of a block's backward: tensors larger than the Infinity Cache are cut to ~100 MB per slice, into at
+    """Batch slices of a block's backward: tensors larger than the Infinity Cache are cut to ~200 MB per slice, into at
     most 8 launches (more, smaller launches cost more than the cache gives back: 8 slices of the 224x224 first block,
-    32 images each, measured +2.5 %), and only into equal slices."""
+    32 images each, measured +2.5 %), and only into equal slices.  (~100 MB = 4 slices of the 224x224 first block until
+    that block's two gradients came from one kernel; since then 2 slices of 209 MB measure 0.5-0.8 % faster:
+    3.949 / 3.946 / 3.951 against 3.974 / 3.986 / 3.983 ms/step, 150-step runs alternated on one box.)"""
     if BWD_SLICES == 1 or nbytes < BWD_SLICE_MIN_MB * 1e6:
         return 1
     S = BWD_SLICES
     if S == 0:
         S = 2
-        while S < 8 and nbytes / S > 110e6:
+        while S < 8 and nbytes / S > 220e6:
             S *= 2
     while S > 1 and B % S:
         S //= 2

@@ -633,3 +633,28 @@ def test_deferred_weight_gradient_reduction_is_bit_identical(prec, streams, monk
         outs.append({k: p.grad.clone() for k, p in m.named_parameters()})
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('cin,cout,H,W', [(256, 256, 12, 12), (64, 128, 10, 7), (128, 64, 6, 14)])
+def test_paired_and_unpaired_tiles_store_the_same_bits(prec, cin, cout, H, W):
+    """Two images per tile (conv.hip, ConvArgs::seam) against one image per tile on RANDOM data: an even batch is paired,
+    the same images in an odd batch are not - outputs bit for bit (training form with statistics, eval form with the
+    ReLU), statistics equal up to the fp32 order of their partial rows (one row per pair instead of per image)."""
+    from vqa_amd import cnn as C
+    dt = DT[prec]
+    torch.manual_seed(cin + H)
+    x = torch.randn(6, H, W, cin, device='cuda').to(dt)
+    w = torch.randn(cout, cin, 3, 3, device='cuda') * 0.05
+    bias = torch.randn(cout, device='cuda')
+    wpk = C.pack_weights(w, cin, dt, dgrad=False)
+    y6, s6 = C.conv_fwd(x, wpk, bias, cout, 0, True)
+    y5, s5 = C.conv_fwd(x[:5].contiguous(), wpk, bias, cout, 0, True)
+    assert s6.shape[0] == 3 and s5.shape[0] == 5           # (pairs / images: the forms really differ)
+    assert torch.equal(y6[:5], y5)
+    y1, s1 = C.conv_fwd(x[5:].contiguous(), wpk, bias, cout, 0, True)
+    tot = s5.double().sum(0) + s1.double().sum(0)
+    assert torch.allclose(s6.double().sum(0), tot, rtol=1e-5, atol=1e-3)
+    r6, _ = C.conv_fwd(x, wpk, bias, cout, 0, False, relu=True)
+    r5, _ = C.conv_fwd(x[:5].contiguous(), wpk, bias, cout, 0, False, relu=True)
+    assert torch.equal(r6[:5], r5) and torch.equal(r6, torch.clamp_min(y6, 0))

@@ -108,10 +108,13 @@ int vqa_conv3x3_first_wgrad_bn(void* stream, int in_dtype, const void* images, c
 /* Conv2d weight gradient (autograd of cnn.py:23-40): dw [Cout][Cin_real][3][3] f32 = sum over pixels of dy (x) x.
  * `part` is a [G][Cout][9][Cin] f32 workspace (one partial slab per workgroup group, summed in fixed order; with
  * dw == NULL the sum is left to vqa_conv3x3_wgrad_reduce_all).
- * in_scale / in_shift: as in vqa_conv3x3_fwd (x = the previous conv's raw output, pad == 0). */
+ * in_scale / in_shift: as in vqa_conv3x3_fwd (x = the previous conv's raw output, pad == 0).
+ * seam > 0: two images per tile, as vqa_conv3x3_fwd pairs them (a pad-0 map small enough for two in a tile) - here the
+ * CALLER passes the pairs' geometry: B = images / 2, IH = 2 x the image's, OH = 2 x the real OH + 2, R >= OH (one tile
+ * per pair), seam = the real OH; x and dy are the ordinary tensors (consecutive images are contiguous).  Same sums. */
 int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const void* dy, float* part, float* dw, int G, int B,
                       int IH, int IW, int Cin, int Cin_real, int OH, int OW, int Cout, int pad, int R, int CW,
-                      const float* in_scale, const float* in_shift);
+                      const float* in_scale, const float* in_shift, int seam);
 /* dw == NULL in vqa_conv3x3_wgrad: the partial slabs are left in `part` and this call reduces the slabs of n layers in
  * ONE launch (nine dependent little launches per training step otherwise).  part / dw: host arrays of n device
  * pointers; desc: host array of n x 4 ints (G, Cout, Cin, Cin_real).  Same sums in the same order per output. */

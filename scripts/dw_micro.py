@@ -29,7 +29,7 @@ for B, c, H in ((64, 16, 226), (256, 32, 114)):
     coef = torch.stack([torch.rand(c) + 0.5, torch.randn(c) * 0.4, torch.randn(c) * 0.3, torch.rand(c) + 0.7]).cuda()
     wd = C.pack_weights(w.cuda(), c, dt, dgrad=True)
     dx = torch.empty(B, H, H, c, device='cuda', dtype=dt)
-    R, CW, gw = C._wgrad_geom(y_lo, dy)
+    R, CW, gw = C._wgrad_geom(y_lo, dy)[:3]
     part = torch.empty(gw, c, 9, c, device='cuda')
     t_d = timed(lambda: C.conv_fwd(dy, wd, None, c, 2, False, kind='dgrad', bst=(y_lo, coef), out=dx))
     t_w = timed(lambda: C.conv_wgrad(y_lo, dy, c, 0, in_coeffs=(coef[0], coef[1]), part_out=part))

@@ -658,3 +658,15 @@ def test_paired_and_unpaired_tiles_store_the_same_bits(prec, cin, cout, H, W):
     r6, _ = C.conv_fwd(x, wpk, bias, cout, 0, False, relu=True)
     r5, _ = C.conv_fwd(x[:5].contiguous(), wpk, bias, cout, 0, False, relu=True)
     assert torch.equal(r6[:5], r5) and torch.equal(r6, torch.clamp_min(y6, 0))
+    # the weight gradient pairs the same way (bf16; vqa_conv3x3_wgrad's seam): a sum over the batch, so the paired call
+    # on six images must equal the unpaired calls on five + one up to the fp32 order of the pixel reduction - plain and
+    # with the previous layer's BatchNorm + ReLU applied to x on the way in
+    dy = torch.randn(6, H - 2, W - 2, cout, device='cuda').to(dt)
+    coef = (torch.rand(cin, device='cuda') + 0.5, torch.randn(cin, device='cuda') * 0.3)
+    for ic in (None, coef):
+        if prec == 'bf16':
+            assert C._wgrad_geom(x, dy, 0)[3] == H - 2 and C._wgrad_geom(x[:5], dy[:5], 0)[3] == 0
+        d6 = C.conv_wgrad(x, dy, cin, 0, in_coeffs=ic)
+        d51 = (C.conv_wgrad(x[:5].contiguous(), dy[:5].contiguous(), cin, 0, in_coeffs=ic) +
+               C.conv_wgrad(x[5:].contiguous(), dy[5:].contiguous(), cin, 0, in_coeffs=ic))
+        assert float((d6 - d51).abs().max()) <= 2e-6 * float(d51.abs().max()) * (6 * H * W) ** 0.5

@@ -186,16 +186,30 @@ def _wgrad_family(cin, cout):
     return 'conv3x3_wgrad_deep' if (cin >= 32 and cout >= 64) else 'conv3x3_wgrad'
 
 
-def wgrad_rows(x, dy):
+def wgrad_rows(x, dy, pad=None):
     """G of conv_wgrad for these shapes (rows of its partial-slab workspace)."""
-    return _wgrad_geom(x, dy)[2]
+    return _wgrad_geom(x, dy, pad)[2]
 
 
-def _wgrad_geom(x, dy):
+# two images per tile in the weight gradient of a small pad-0 map (vqa_conv3x3_wgrad's seam; the forward pairs inside
+# the library): the 10x10 map of the last conv fills 100 of a tile's 256 reduction pixels - 4 steps of 32 for 3.1 steps
+# of work, and a patch + dy staging round per image
+WGRAD_PAIR = os.environ.get('VQA_WGRAD_PAIR', '1') != '0'
+
+
+def _wgrad_geom(x, dy, pad=None):
+    """-> (R, CW, G, seam, (B, IH, OH) as passed to the library: those of the PAIRS when seam > 0)."""
     B, IH, IW, cin = x.shape
     _, OH, OW, cout = dy.shape
     mt = 256 if x.dtype == torch.bfloat16 else 128
-    R, CW = pick_tile(OH, OW, mt, 384 if mt == 256 else 320)
+    pmax = 384 if mt == 256 else 320
+    R, CW = pick_tile(OH, OW, mt, pmax)
+    seam = 0
+    if (WGRAD_PAIR and pad == 0 and R >= OH and CW >= OW and B % 2 == 0 and (2 * OH + 2) * CW <= mt and
+            2 * IH * (CW + 2) <= pmax):
+        seam, B, IH, OH = OH, B // 2, 2 * IH, 2 * OH + 2
+        R = OH
+    geo = (B, IH, OH)
     tiles = B * (-(-OH // R)) * (-(-OW // CW))
     ck = _ck(cin, x.dtype)
     pairs = (-(-cout // 64)) * (cin // ck)
@@ -215,7 +229,7 @@ def _wgrad_geom(x, dy):
     if per_cu - WGRAD_RESERVE >= 2:
         per_cu -= WGRAD_RESERVE
     G = max(1, min(tiles, (256 * per_cu) // pairs if pairs <= 256 * per_cu else 1))
-    return R, CW, G
+    return R, CW, G, seam, geo
 
 
 def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None, defer=None, part_out=None):
@@ -225,21 +239,21 @@ def conv_wgrad(x, dy, cin_real, pad, out=None, in_coeffs=None, defer=None, part_
     caller reduces the slabs of all slices at once, wgrad_reduce_all); returns None."""
     B, IH, IW, cin = x.shape
     _, OH, OW, cout = dy.shape
-    R, CW, G = _wgrad_geom(x, dy)
+    R, CW, G, seam, (gB, gIH, gOH) = _wgrad_geom(x, dy, pad)
     isc, ish = in_coeffs if in_coeffs is not None else (None, None)
     if part_out is not None:
         assert tuple(part_out.shape) == (G, cout, 9, cin) and part_out.is_contiguous()
         tag = lambda: _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), cout * cin_real * 36,
                                 kernel=_wgrad_family(cin, cout))
-        L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part_out, None, G, B, IH, IW, cin, cin_real,
-               OH, OW, cout, pad, R, CW, isc, ish, tag=tag)
+        L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part_out, None, G, gB, gIH, IW, cin, cin_real,
+               gOH, OW, cout, pad, R, CW, isc, ish, seam, tag=tag)
         return None
     part = P.empty((G, cout, 9, cin), torch.float32, x.device)
     dw = out if out is not None else P.empty((cout, cin_real, 3, 3), torch.float32, x.device)
     tag = lambda: _conv_tag('wgrad', B, OH, OW, cin_real, cout, x, dy.numel() * dy.element_size(), dw.numel() * 4,
                             kernel=_wgrad_family(cin, cout))
-    L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw if defer is None else None, G, B, IH, IW, cin, cin_real,
-           OH, OW, cout, pad, R, CW, isc, ish, tag=tag)
+    L.call('vqa_conv3x3_wgrad', L.dt(x), x, dy, part, dw if defer is None else None, G, gB, gIH, IW, cin, cin_real,
+           gOH, OW, cout, pad, R, CW, isc, ish, seam, tag=tag)
     if defer is not None:
         defer.append((part, dw, G, cout, cin, cin_real))
     return dw
@@ -435,7 +449,7 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, gdst, first=False, wpk_
         both = bst is not None and in_coeffs is not None and _same(bst[0], x) and dgrad_wgrad_ok(y, cin, pad)
         gd = _plan(L.dt(y), Bs, H, W, C, IH, IW, cin, 2 - pad, *pick_tile(IH, IW), 3 if both else (2 if bst else 0))
         below = P.empty((S * gd, cin, 2), torch.float32, dev) if bst else None
-        gw = gd if both else wgrad_rows(x[:Bs], dys[:Bs])
+        gw = gd if both else wgrad_rows(x[:Bs], dys[:Bs], pad)
         part_w = P.empty((S * gw, C, 9, cin), torch.float32, dev)
         for si in range(S):
             sl = slice(si * Bs, (si + 1) * Bs)
@@ -646,7 +660,7 @@ def _knobs():
     return (WGRAD_STREAM, FUSE_BN_FWD, FUSE_BN_BWD, FUSE_FIRST_BN, FUSE_POOL_BWD, DEFER_WGRAD_REDUCE, BWD_SLICES,
             BWD_SLICE_MIN_MB, WGRAD_RESERVE, FIRST_WGRAD_MAIN, FIRST_RESERVE, WGRAD_HOLD_FROM, WGRAD_RELEASE_AT,
             FUSE_DGRAD_WGRAD,
-            WGRAD_COF4)
+            WGRAD_COF4, WGRAD_PAIR)
 
 
 def out_regions(size, padding):

@@ -883,6 +883,7 @@ struct WgradArgs {
     const float* in_scale;   // XF kernels: x is the previous conv's raw output, the input is relu(in_scale*x + in_shift)
     const float* in_shift;   // (see ConvArgs; pad == 0 only)
     int rev;                 // walk the pixel tiles back to front (unit_walk, common.h)
+    int seam;                // two images per tile (see ConvArgs::seam): the real OH; B, IH, OH above are the pairs'
 };
 
 // One workgroup: NB = 64 output channels x CK input channels x 9 taps, looping over pixel tiles
@@ -959,8 +960,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     for (int j = 0; j < NDV; ++j) {
         const int i = tid + j * 256, m = i >> dsh, vv = i & (dvp - 1);
         const int pr = fastdiv(m, a.CW, a.inv_cw), pc = m - pr * a.CW;
-        drc[j] = ((m < MT ? pr : 0x4000) << 16) | pc;
-        drel[j] = ((pr * a.OW + pc) * a.Cout + co0 + vv * VEC) * (int)sizeof(T);                        // bytes
+        // (two images per tile: dy has no rows for the two output rows that straddle the images - they are fetched as
+        // zeros - and the second image's rows sit two rows further up in memory than in the tile)
+        const bool gap = a.seam && (unsigned)(pr - a.seam) < 2u;
+        const int prm = pr - ((a.seam && pr >= a.seam + 2) ? 2 : 0);
+        drc[j] = ((m < MT && !gap ? pr : 0x4000) << 16) | pc;
+        drel[j] = ((prm * a.OW + pc) * a.Cout + co0 + vv * VEC) * (int)sizeof(T);                       // bytes
     }
     if constexpr (XF) {
         if (tid < CK) { coefl[tid] = a.in_scale[ci0 + tid]; coefl[CK + tid] = a.in_shift[ci0 + tid]; }
@@ -977,7 +982,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
     // out-of-image patch vectors and dy rows beyond the tile / image are fetched at the buffers' sizes: the hardware
     // returns zeros for them (no clamped address, no mask at the LDS write)
     const unsigned xbytes = (unsigned)a.B * a.IH * a.IW * a.Cin * (unsigned)sizeof(T);      // (launcher: both < 4 GiB)
-    const unsigned dbytes = (unsigned)a.B * a.OH * a.OW * a.Cout * (unsigned)sizeof(T);
+    const int ohm = a.seam ? 2 * a.seam : a.OH;                    // dy rows per image (pair) in memory
+    const unsigned dbytes = (unsigned)a.B * ohm * a.OW * a.Cout * (unsigned)sizeof(T);
     const __amdgpu_buffer_rsrc_t xbuf = buffer_of(a.x, xbytes), dbuf = buffer_of(a.dy, dbytes);
     uint4 pv[NPV], dv[NDV];
     auto fetch = [&](int t) {
@@ -985,7 +991,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(WgradArgs a) {
         const int tyy = fastdiv(tl, a.tiles_x, a.inv_tx);
         const int oy0 = tyy * a.R, ox0 = (tl - tyy * a.tiles_x) * a.CW;
         const unsigned xorg = (unsigned)((b * a.IH + oy0) * a.IW + ox0) * a.Cin * (unsigned)sizeof(T);
-        const unsigned dorg = (unsigned)((b * a.OH + oy0) * a.OW + ox0) * a.Cout * (unsigned)sizeof(T);
+        const unsigned dorg = (unsigned)((b * ohm + oy0) * a.OW + ox0) * a.Cout * (unsigned)sizeof(T);
 #pragma unroll
         for (int j = 0; j < NPV; ++j) {
             const bool ok = (unsigned)(oy0 + (pyx[j] >> 16)) < (unsigned)a.IH &&
@@ -1386,8 +1392,10 @@ extern "C" int vqa_conv3x3_dgrad_wgrad(void* stream, int dtype, const void* dy, 
 
 extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const void* dy, float* part, float* dw,
                                  int G, int B, int IH, int IW, int Cin, int Cin_real, int OH, int OW, int Cout,
-                                 int pad, int R, int CW, const float* in_scale, const float* in_shift) {
+                                 int pad, int R, int CW, const float* in_scale, const float* in_shift, int seam) {
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || G < 1) return VQA_ERR_ARG;
+    // two images per tile: B, IH, OH are those of the pairs; one tile per pair, no zero border between the images
+    if (seam < 0 || (seam && (pad != 0 || OH != 2 * seam + 2 || R < OH || CW < OW))) return VQA_ERR_ARG;
     if ((in_scale != nullptr) != (in_shift != nullptr) || (in_scale && pad != 0)) return VQA_ERR_ARG;
     const bool xf = in_scale != nullptr;
     {   // x and dy are addressed through 32-bit byte offsets (buffer resources)
@@ -1401,7 +1409,7 @@ extern "C" int vqa_conv3x3_wgrad(void* stream, int dtype, const void* x, const v
     // fastdiv (common.h): float quotient + signed 24-bit products - tile numbers below 2^22
     if ((long)B * tx_ * ty_ >= (1 << 22)) return VQA_ERR_ARG;
     WgradArgs a{x, dy, part, B, IH, IW, Cin, OH, OW, Cout, pad, R, CW, tx_, ty_,
-                1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), in_scale, in_shift, vqa_walk_rev(8)};
+                1.0f / CW, 1.0f / (CW + 2), 1.0f / tx_, 1.0f / (tx_ * ty_), in_scale, in_shift, vqa_walk_rev(8), seam};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int MT = R * CW, PPIX = (R + 2) * (CW + 2);
     int status = VQA_ERR_ARG;

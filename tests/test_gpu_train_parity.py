@@ -417,12 +417,16 @@ def test_bf16_trajectory_tracks_fp32(tmp_path):
     assert abs(eval_loss['fp32'] - eval_loss['bf16']) < TRAJ_EVAL_LOSS * eval_loss['fp32']
 
 
-# bands of test_bf16_trajectory_tracks_fp32 (measured values in DESIGN.md section 2).  The eval-mode figures after 40
-# steps are only as reproducible as the fp32 path is against ITSELF: the same fp32 run with another fp32 summation order
-# of one layer's BatchNorm statistics (two images per conv tile on / off, batch slices, fused / separate reduce passes:
-# gradients equal to 1e-7 in step 1, 1e-3 in step 2, 4e-2 in step 3 - Adamax's first update is lr * sign(g)) ends at an
-# eval loss per sample between 16.1 and 18.2 and a soft accuracy between 0.141 and 0.168; bf16: 16.05-16.46, 0.152-0.160.
-TRAJ_BAND, TRAJ_FINAL, TRAJ_ACC_DELTA, TRAJ_EVAL_LOSS = 0.35, 0.05, 0.04, 0.15
+# bands of test_bf16_trajectory_tracks_fp32 (measured values in DESIGN.md section 2).  The pinned statement is the
+# TRAINING-loss band (stable across every variant of the library measured: max 0.26-0.28 at step 17, 0.055-0.067 over
+# the first ten steps) and the final mean loss.  The eval-mode figures after 40 steps are weak evidence and bounded as
+# such: they are only as reproducible as the fp32 path is against ITSELF - the same fp32 run with another fp32
+# summation order of one layer's sums (two images per conv tile on / off in the forward or the weight gradient, batch
+# slices, fused / separate reduce passes: gradients equal to 1e-7 in step 1, 1e-3 in step 2, 4e-2 in step 3 - Adamax's
+# first update is lr * sign(g)) ends at an eval loss per sample between 16.1 and 18.7 (bf16: 15.8-16.5), and a soft
+# accuracy of 0.14-0.19 on 256 samples of a one-in-seven task is within two standard errors (0.023 each) of chance:
+# the accuracy bound is three standard errors of a difference, 3 * sqrt(2 * 0.16 * 0.84 / 256) = 0.097.
+TRAJ_BAND, TRAJ_FINAL, TRAJ_ACC_DELTA, TRAJ_EVAL_LOSS = 0.35, 0.05, 0.097, 0.25
 
 
 def test_clip_adamax_vs_torch_optim():

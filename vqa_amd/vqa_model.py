@@ -95,9 +95,9 @@ HEAD_LAYERS = ['linear_inside_relu_attention', 'linear_after_relu_attention', 'l
 HEAD_DQ_STREAM = os.environ.get('VQA_HEAD_DQ_STREAM', '0') != '0'
 # VQA_HEAD_DQ_SIDE=1: those three launches lead the head's parameter-gradient work on the WEIGHT-GRADIENT stream (which
 # that work is ordered behind the chain by one event anyway) and the question encoder's stream waits for them: the chain
-# to the CNN's backward neither runs them nor records anything more.  Off: same-box A/B, 2 alternations of 60 steps,
-# 4.048 / 4.075 against 4.018 / 4.098 ms/step - 29 us of kernels less on the chain and nothing gained (what the chain
-# sheds still runs beside it on the same CUs).
+# to the CNN's backward neither runs them nor records anything more.  Off: 29 us of kernels less on the chain buy 0 to
+# 0.3 % (150-step runs alternated on one box: 3.954-3.966 against 3.956-3.959 ms/step on a fast box, 4.057-4.075
+# against 4.070-4.090 on a slower one) - what the chain sheds still runs beside it on the same CUs.
 HEAD_DQ_SIDE = os.environ.get('VQA_HEAD_DQ_SIDE', '0') != '0'
 # VQA_HEAD_WN_EARLY=1: the six weight norms of the head (W = g v / ||v||: two launches, ~30 us, parameters only) are
 # issued at the start of forward() on the weight-gradient stream, which is idle during the forward pass, instead of on

@@ -156,10 +156,15 @@ int vqa_bn_bwd_finalize(void* stream, const float* part, int rows, int C, double
 /* MFMA GEMM with fused epilogue.  trans = 0: C[M,N] = A[M,K] * B[N,K]^T (nn.Linear forward, input gradients with a
  * pre-transposed weight).  trans = 1: C[M,N] = A[K,M]^T * B[K,N] (weight gradients).  Epilogue: + bias[n],
  * + rowadd[m / rowadd_group][n], activation (act = 1 ReLU, 3 SELU), C += (accumulate = 1), optional bf16 copy C2.
- * splits > 1: split-K over grid.z with raw partial sums in splitk_ws [splits][M][N] f32, summed in slice order. */
+ * splits > 1: split-K over grid.z with raw partial sums in splitk_ws [splits][M][N] f32, summed in slice order.
+ * emul [M][ldm] f32 / emode (NULL / 0: off): an elementwise factor applied last in the epilogue, for the head's
+ * elementwise steps between its GEMMs (vqa_model.py:97-101).  emode 1: C2 = bf16(x * emul) while C = x - the Hadamard
+ * product of the two projections as the bf16 copy of the second one (C2 required); emode 16 + act (act = 1 ReLU, 3
+ * SELU): C = x * act'(emul), the derivative taken from the activation's OUTPUT emul - vqa_relu_bwd without a mask in
+ * the GEMM that forms its incoming gradient.  Same arithmetic, same bits as the separate kernels. */
 int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
              void* C, int ldc, int c_dtype, const float* bias, const float* rowadd, int rowadd_group, int act,
-             int accumulate, void* C2, int ldc2, float* splitk_ws, int splits);
+             int accumulate, void* C2, int ldc2, float* splitk_ws, int splits, const float* emul, int ldm, int emode);
 /* The classifier GEMM with the loss in its epilogue (vqa_model.py:103 self.fc(...) + :215 BCEWithLogitsLoss(sum)):
  * logits [M][ldc] f32 = A[M,K] * W[N,K]^T written once, loss[0] and dlogits [M][ldd] = sigmoid(logits) - target formed
  * from the accumulators (no second pass over logits / targets).  target: dense f32 [M][ldt]; or NULL with the sparse

@@ -16,7 +16,7 @@ def _gemm(A, B, trans, out_dtype=torch.float32, bias=None, rowadd=None, group=1,
     C = acc.clone() if acc is not None else torch.empty(M, N, device='cuda', dtype=out_dtype)
     ws = torch.empty(splits, M, N, device='cuda') if splits > 1 else None
     L.call('vqa_gemm', L.dt(A), int(trans), M, N, K, A, A.stride(0), B, B.stride(0), C, C.stride(0), L.dt(C),
-           bias, rowadd, group, act, int(acc is not None), None, 0, ws, splits)
+           bias, rowadd, group, act, int(acc is not None), None, 0, ws, splits, None, 0, 0)
     return C
 
 
@@ -119,3 +119,36 @@ def test_colsum(dtype, M, N, pad, off):
     xr = (torch.randn(M, N, device='cuda') * 0.5).to(dtype)
     want = xr.double().sum(0)
     assert float((ops.colsum(xr).double() - want).abs().max()) <= 2e-6 * float(xr.float().abs().sum(0).max()) + 1e-6
+
+
+@pytest.mark.parametrize('M,N,K,splits', [(256, 1024, 1024, 1), (256, 1024, 3129 + 7, 5), (100, 52, 304, 1), (300, 200, 512, 2)])
+def test_gemm_epilogue_multiplier(M, N, K, splits):
+    """vqa_gemm's emul / emode against the separate elementwise kernels they replace in the head (vqa_hadamard_fwd,
+    vqa_relu_bwd without a mask): the whole-tile epilogue of the small-M path, the ragged-tile fallback and the
+    split-K reduce pass - bit for bit."""
+    from vqa_amd import _lib as L, ops
+    torch.manual_seed(M + K)
+    A = torch.randn(M, K, device='cuda').bfloat16()
+    B = torch.randn(N, K, device='cuda').bfloat16() * 0.05
+    bias = torch.randn(N, device='cuda')
+    other = torch.randn(M, N + 8, device='cuda')[:, :N]              # (row-strided multiplier)
+    plain = ops.gemm(A, B, bias=bias, act=1, splits=splits)
+    # emode 1: the bf16 copy is the product, C itself is untouched
+    c2 = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    out = ops.gemm(A, B, bias=bias, act=1, splits=splits, c2=c2, emul=other, emode=1)
+    want = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    L.call('vqa_hadamard_fwd', L.BF16, other.contiguous(), plain, None, M * N, want, None)
+    assert torch.equal(out, plain) and torch.equal(c2, want)
+    # emode 16 + act: C scaled by the activation's derivative taken from another tensor (the activation's output)
+    for act in (1, 3):
+        y = torch.randn(M, N, device='cuda')
+        for dt in (torch.bfloat16, torch.float32):
+            raw = ops.gemm(A, B, splits=splits)
+            got = ops.gemm(A, B, splits=splits, out_dtype=dt, emul=y, emode=16 + act)
+            ref = torch.empty(M, N, device='cuda', dtype=dt)
+            L.call('vqa_relu_bwd', L.dt(ref), raw, y, None, M * N, ref, act)
+            assert torch.equal(got, ref)
+    with pytest.raises(L.VqaHipError):
+        ops.gemm(A, B, emul=other, emode=1)                          # emode 1 needs the bf16 copy
+    with pytest.raises(L.VqaHipError):
+        ops.gemm(A, B, emul=other, emode=7)

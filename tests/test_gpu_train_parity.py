@@ -499,12 +499,13 @@ def test_gradient_accumulation_with_side_streams(prec, tmp_path, monkeypatch):
     assert torch.equal(out[0][3], out[1][3]) and torch.equal(out[0][3], out[0][1]['linear_inside_relu_last.weight_v'])
 
 
-@pytest.mark.parametrize('knob', ['HEAD_DQ_SIDE', 'HEAD_WN_EARLY'])
+@pytest.mark.parametrize('knob', ['HEAD_DQ_SIDE', 'HEAD_WN_EARLY', 'HEAD_FUSE_ELEMENTWISE'])
 def test_head_stream_knobs_are_bit_identical(knob, tmp_path, monkeypatch):
     """The two measured-and-not-kept placements of head work (vqa_model.HEAD_DQ_SIDE: the question gradient leads the
     parameter-gradient work on the weight-gradient stream; HEAD_WN_EARLY: the weight norms issued at the start of the
-    forward on that stream) change streams, not launches: logits and every gradient bit for bit, two steps in a row
-    (the second starts while the first one's side-stream work may still be running)."""
+    forward on that stream) change streams, not launches, and HEAD_FUSE_ELEMENTWISE (the default: vqa_hadamard_fwd and
+    vqa_relu_bwd as epilogues of the GEMMs beside them) changes launches, not arithmetic: logits and every gradient bit
+    for bit, two steps in a row (the second starts while the first one's side-stream work may still be running)."""
     import vqa_model
     from vqa_amd import vqa_model as VM
     c = load_case('h64_p5_max')

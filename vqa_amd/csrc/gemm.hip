@@ -30,6 +30,12 @@ struct GemmArgs {
     const float* target; int ldt;
     float* dlogits; int ldd;
     double* loss_part;
+    // epilogue multiplier emul [M][ldm] f32 (the head's elementwise kernels between its M = 256 GEMMs are launch latency
+    // on the one phase of the step where nothing else runs: ~9 us each).  emode 1: the bf16 copy C2 is x * emul while C
+    // stays x (vqa_model.py:97-99: C = relu(W_q q + b), C2 = its Hadamard product with the image projection);
+    // emode 16 + act: C = x * act'(emul), act' from the activation's OUTPUT (the backward of vqa_model.py:101: the
+    // gradient w.r.t. relu's input from the GEMM that forms the gradient w.r.t. its output).
+    const float* emul; int ldm; int emode;
 };
 
 template <typename T>
@@ -67,6 +73,7 @@ __device__ __forceinline__ float epilogue_store(const GemmArgs& g, TC* C, int m,
             if (RICH) { if (g.act == 1 || g.act == 3) x = act_apply(x, g.act); }
             else if (g.act == 1) x = fmaxf(x, 0.f);
             if (g.accumulate) x += to_f32(C[(long)m * g.ldc + ne]);
+            if (g.emode >= 16) x *= act_grad(g.emul[(long)m * g.ldm + ne], g.emode - 16);
             if (RICH && g.act == 2) {              // the arithmetic of bce_partial (misc.hip), element for element
                 const float t = g.target ? g.target[(long)m * g.ldt + ne] : 0.f;
                 const float ex = __expf(-fabsf(x));
@@ -76,15 +83,18 @@ __device__ __forceinline__ float epilogue_store(const GemmArgs& g, TC* C, int m,
         }
         v[e] = x;
     }
+    float v2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v2[e] = (g.emode == 1 && n + e < g.N) ? v[e] * g.emul[(long)m * g.ldm + n + e] : v[e];
     if (vec_ok && n + 3 < g.N) {
         store_vec4<TC>(C + (long)m * g.ldc + n, v);
-        if (g.C2) store_vec4<bf16>(g.C2 + (long)m * g.ldc2 + n, v);
+        if (g.C2) store_vec4<bf16>(g.C2 + (long)m * g.ldc2 + n, v2);
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (n + e < g.N) {
                 C[(long)m * g.ldc + n + e] = from_f32<TC>(v[e]);
-                if (g.C2) g.C2[(long)m * g.ldc2 + n + e] = (bf16)v[e];
+                if (g.C2) g.C2[(long)m * g.ldc2 + n + e] = (bf16)v2[e];
             }
     }
     return loss;
@@ -392,6 +402,11 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += to_f32(C[(long)m * g.ldc + n + e]);
                     }
+                    if (g.emode >= 16) {
+                        const float* em = g.emul + (long)m * g.ldm + n;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= act_grad(em[e], g.emode - 16);
+                    }
                 }
                 *reinterpret_cast<float4*>(ew + r * EROW + (j * 16 + q * 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -403,7 +418,15 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
                 if (m < g.M) {
                     const float o[4] = {t.x, t.y, t.z, t.w};
                     store_vec4<TC>(C + (long)m * g.ldc + nb + c * 4, o);
-                    if (g.C2) store_vec4<bf16>(g.C2 + (long)m * g.ldc2 + nb + c * 4, o);
+                    if (g.C2) {
+                        if (g.emode == 1) {
+                            const float* em = g.emul + (long)m * g.ldm + nb + c * 4;
+                            const float o2[4] = {o[0] * em[0], o[1] * em[1], o[2] * em[2], o[3] * em[3]};
+                            store_vec4<bf16>(g.C2 + (long)m * g.ldc2 + nb + c * 4, o2);
+                        } else {
+                            store_vec4<bf16>(g.C2 + (long)m * g.ldc2 + nb + c * 4, o);
+                        }
+                    }
                 }
             }
         }
@@ -453,7 +476,11 @@ __global__ void gemm_splitk_reduce(GemmArgs g, int splits) {
             if (g.rowadd) x[e] += g.rowadd[(m / g.rowadd_group) * g.N + n + e];
             if (g.act == 1 || g.act == 3) x[e] = act_apply(x[e], g.act);
             if (g.accumulate) x[e] += to_f32(C[m * g.ldc + n + e]);
+            if (g.emode >= 16) x[e] *= act_grad(g.emul[m * g.ldm + n + e], g.emode - 16);
         }
+        float x2[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) x2[e] = g.emode == 1 ? x[e] * g.emul[m * g.ldm + n + e] : x[e];
         if constexpr (VEC4) {
             if constexpr (sizeof(TC) == 4) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + m * g.ldc + n) = make_float4(x[0], x[1], x[2], x[3]);
@@ -462,12 +489,12 @@ __global__ void gemm_splitk_reduce(GemmArgs g, int splits) {
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(C) + m * g.ldc + n) = o;
             }
             if (g.C2) {
-                bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
+                bf16x4 o = {(bf16)x2[0], (bf16)x2[1], (bf16)x2[2], (bf16)x2[3]};
                 *reinterpret_cast<bf16x4*>(g.C2 + m * g.ldc2 + n) = o;
             }
         } else {
             C[m * g.ldc + n] = from_f32<TC>(x[0]);
-            if (g.C2) g.C2[m * g.ldc2 + n] = (bf16)x[0];
+            if (g.C2) g.C2[m * g.ldc2 + n] = (bf16)x2[0];
         }
     }
 }
@@ -534,8 +561,10 @@ int launch(hipStream_t s, int trans, const GemmArgs& g, int splits) {
 extern "C" int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K, const void* A, int lda,
                         const void* B, int ldb, void* C, int ldc, int c_dtype, const float* bias,
                         const float* rowadd, int rowadd_group, int act, int accumulate, void* C2, int ldc2,
-                        float* splitk_ws, int splits) {
+                        float* splitk_ws, int splits, const float* emul, int ldm, int emode) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return VQA_ERR_ARG;
+    if (emode != 0 && emode != 1 && emode != 16 + VQA_ACT_RELU && emode != 16 + VQA_ACT_SELU) return VQA_ERR_ARG;
+    if ((emode != 0) != (emul != nullptr) || (emode && ldm < N) || (emode == 1 && !C2)) return VQA_ERR_ARG;
     if (rowadd && rowadd_group <= 0) return VQA_ERR_ARG;
     if (splits < 1 || (splits > 1 && !splitk_ws)) return VQA_ERR_ARG;
     const int kc = dtype == VQA_BF16 ? 128 : 16;   // split boundaries on whole pipeline stages
@@ -543,7 +572,8 @@ extern "C" int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K,
     splits = splits > 1 ? (K + kper - 1) / kper : 1;
     if (act != 0 && act != 1 && act != 3) return VQA_ERR_ARG;
     GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, bias, rowadd, rowadd_group, act, accumulate,
-               static_cast<bf16*>(C2), ldc2, splits > 1 ? splitk_ws : nullptr, kper, nullptr, 0, nullptr, 0, nullptr};
+               static_cast<bf16*>(C2), ldc2, splits > 1 ? splitk_ws : nullptr, kper, nullptr, 0, nullptr, 0, nullptr,
+               emul, ldm, emode};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == VQA_F32 && c_dtype == VQA_F32) return launch<float, float>(s, trans, g, splits);
     if (dtype == VQA_BF16 && c_dtype == VQA_F32) return launch<bf16, float>(s, trans, g, splits);
@@ -601,7 +631,7 @@ extern "C" int vqa_fc_bce(void* stream, int dtype, int M, int N, int K, const vo
     }
     if (tiles + M > vqa_fc_bce_part(M, N)) return VQA_ERR_ARG;
     GemmArgs g{M, N, K, A, lda, W, ldw, logits, ldc, nullptr, nullptr, 1, 2, 0, nullptr, 0, nullptr, K,
-               target, ldt, dlogits, ldd, part};
+               target, ldt, dlogits, ldd, part, nullptr, 0, 0};
     int st;
     if (dtype == VQA_F32) st = launch<float, float>(s, 0, g, 1);
     else if (dtype == VQA_BF16) st = launch<bf16, float>(s, 0, g, 1);

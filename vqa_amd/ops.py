@@ -12,10 +12,11 @@ def pad8(n):
 
 
 def gemm(A, B, trans=False, M=None, N=None, K=None, out=None, out_dtype=torch.float32, bias=None, rowadd=None,
-         group=1, act=0, accumulate=False, c2=None, splits=None):
+         group=1, act=0, accumulate=False, c2=None, splits=None, emul=None, emode=0):
     """NT: out[M,N] = A[M,K] @ B[N,K]^T.   TN (trans=True): out[M,N] = A[K,M]^T @ B[K,N].
     A / B may be row-strided views (stride(1) == 1).  Epilogue: + bias[n] + rowadd[m // group, n], ReLU (act=1),
-    accumulate into `out`, optional bf16 copy `c2`."""
+    accumulate into `out`, optional bf16 copy `c2`; emul / emode: vqa_gemm's epilogue multiplier (emode 1:
+    c2 = bf16(out * emul); emode 16 + act: out *= act'(emul), the derivative from the activation's output)."""
     assert A.stride(1) == 1 and B.stride(1) == 1 and A.dtype == B.dtype
     if trans:
         K = A.shape[0] if K is None else K
@@ -34,7 +35,8 @@ def gemm(A, B, trans=False, M=None, N=None, K=None, out=None, out_dtype=torch.fl
     tag = lambda: dict(kind='tn' if trans else 'nt', shape=f'{M}x{N}x{K}', flops=2.0 * M * N * K,
                bytes=float((M * K + N * K) * A.element_size() + M * N * out.element_size()))
     L.call('vqa_gemm', L.dt(A), int(trans), M, N, K, A, A.stride(0), B, B.stride(0), out, out.stride(0), L.dt(out),
-           bias, rowadd, group, act, int(accumulate), c2, c2.stride(0) if c2 is not None else 0, ws, splits, tag=tag)
+           bias, rowadd, group, act, int(accumulate), c2, c2.stride(0) if c2 is not None else 0, ws, splits,
+           emul, emul.stride(0) if emul is not None else 0, emode, tag=tag)
     return out
 
 

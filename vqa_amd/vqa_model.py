@@ -105,6 +105,10 @@ HEAD_DQ_SIDE = os.environ.get('VQA_HEAD_DQ_SIDE', '0') != '0'
 # 28 MB of bf16 matrices are written 1.2 ms before the head's GEMMs read them, and the CNN's forward evicts them from
 # the Infinity Cache in between (round 1 saw the same with them on the question encoder's stream).
 HEAD_WN_EARLY = os.environ.get('VQA_HEAD_WN_EARLY', '0') != '0'
+# VQA_HEAD_FUSE_ELEMENTWISE=0: vqa_hadamard_fwd / vqa_relu_bwd as launches of their own instead of GEMM epilogues
+# (vqa_gemm's emul / emode).  The head's phase is the one stretch of the step where nothing else runs, so a launch there
+# costs its latency in full: four 256-byte fills put into it cost the step 0.020 ms, ten 0.040 (150-step runs).
+HEAD_FUSE_ELEMENTWISE = os.environ.get('VQA_HEAD_FUSE_ELEMENTWISE', '1') != '0'
 # Head parameter gradients on the weight-gradient stream (see _HeadFunction.backward); VQA_HEAD_WGRAD_STREAM=0: inline
 HEAD_WGRAD_STREAM = os.environ.get('VQA_HEAD_WGRAD_STREAM', '1') != '0'
 
@@ -146,9 +150,14 @@ class _HeadFunction(torch.autograd.Function):
         vhat_t = torch.empty(B, D, device=dev, dtype=dtype)
         L.call('vqa_attn_fwd', L.dt(a), a, w_s, v, B, K, H, D, p, vhat, vhat_t)
         fv = ops.gemm(vhat_t, W_img, bias=b_img, act=act)
-        fq = ops.gemm(q_t, W_q, bias=b_q, act=act)
         m0 = torch.empty(B, H, device=dev, dtype=dtype)
-        L.call('vqa_hadamard_fwd', L.dt(m0), fv, fq, mask1, B * H, m0, add1)
+        if HEAD_FUSE_ELEMENTWISE and mask1 is None and add1 is None and dtype == torch.bfloat16:
+            # no dropout: the Hadamard product leaves the second projection's GEMM as its bf16 copy (one launch less
+            # on the chain between the CNN's forward and backward; same bits as vqa_hadamard_fwd)
+            fq = ops.gemm(q_t, W_q, bias=b_q, act=act, c2=m0, emul=fv, emode=1)
+        else:
+            fq = ops.gemm(q_t, W_q, bias=b_q, act=act)
+            L.call('vqa_hadamard_fwd', L.dt(m0), fv, fq, mask1, B * H, m0, add1)
         m_t = torch.empty(B, H, device=dev, dtype=dtype)
         if mask2 is None and add2 is None and dtype == torch.bfloat16:
             m = ops.gemm(m0, W_last, bias=b_last, act=act, c2=m_t)    # no dropout: the GEMM writes the bf16 copy itself
@@ -195,9 +204,14 @@ class _HeadFunction(torch.autograd.Function):
             if dlogits is None:
                 dlogits = torch.zeros(B, C, device=dev, dtype=torch.float32)
             dl_t = ops.cast_pad(dlogits.contiguous(), dtype, ops.pad8(C))        # [B,C] (padded rows)
-        dm = ops.gemm(dl_t, W_fc_T)                                              # [B,H]
-        dpre_last = new(B, H)
-        L.call('vqa_relu_bwd', L.dt(dpre_last), dm, m, mask2, B * H, dpre_last, act)
+        if HEAD_FUSE_ELEMENTWISE and mask2 is None:
+            # no dropout: the activation's derivative is applied in the epilogue of the GEMM that forms dm (its
+            # split-K reduce pass): one launch less on the chain, same bits as vqa_relu_bwd
+            dpre_last = ops.gemm(dl_t, W_fc_T, out_dtype=dtype, emul=m, emode=16 + act)      # [B,H]
+        else:
+            dm = ops.gemm(dl_t, W_fc_T)                                          # [B,H]
+            dpre_last = new(B, H)
+            L.call('vqa_relu_bwd', L.dt(dpre_last), dm, m, mask2, B * H, dpre_last, act)
         dm0 = ops.gemm(dpre_last, W_last_T)
         dpv, dpq = new(B, H), new(B, H)
         L.call('vqa_hadamard_bwd', L.dt(dpv), dm0, fv, fq, mask1, B * H, dpv, dpq, act)

@@ -161,10 +161,13 @@ int vqa_bn_bwd_finalize(void* stream, const float* part, int rows, int C, double
  * elementwise steps between its GEMMs (vqa_model.py:97-101).  emode 1: C2 = bf16(x * emul) while C = x - the Hadamard
  * product of the two projections as the bf16 copy of the second one (C2 required); emode 16 + act (act = 1 ReLU, 3
  * SELU): C = x * act'(emul), the derivative taken from the activation's OUTPUT emul - vqa_relu_bwd without a mask in
- * the GEMM that forms its incoming gradient.  Same arithmetic, same bits as the separate kernels. */
+ * the GEMM that forms its incoming gradient; emode 32 + act (emul2 [M][ldm] and C2 required): C = x * emul2 *
+ * act'(emul), C2 = bf16(x * emul * act'(emul2)) - vqa_hadamard_bwd without a mask (emul = fv, emul2 = fq).  Same
+ * arithmetic, same bits as the separate kernels. */
 int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
              void* C, int ldc, int c_dtype, const float* bias, const float* rowadd, int rowadd_group, int act,
-             int accumulate, void* C2, int ldc2, float* splitk_ws, int splits, const float* emul, int ldm, int emode);
+             int accumulate, void* C2, int ldc2, float* splitk_ws, int splits, const float* emul, int ldm, int emode,
+             const float* emul2);
 /* The classifier GEMM with the loss in its epilogue (vqa_model.py:103 self.fc(...) + :215 BCEWithLogitsLoss(sum)):
  * logits [M][ldc] f32 = A[M,K] * W[N,K]^T written once, loss[0] and dlogits [M][ldd] = sigmoid(logits) - target formed
  * from the accumulators (no second pass over logits / targets).  target: dense f32 [M][ldt]; or NULL with the sparse

@@ -16,7 +16,7 @@ def _gemm(A, B, trans, out_dtype=torch.float32, bias=None, rowadd=None, group=1,
     C = acc.clone() if acc is not None else torch.empty(M, N, device='cuda', dtype=out_dtype)
     ws = torch.empty(splits, M, N, device='cuda') if splits > 1 else None
     L.call('vqa_gemm', L.dt(A), int(trans), M, N, K, A, A.stride(0), B, B.stride(0), C, C.stride(0), L.dt(C),
-           bias, rowadd, group, act, int(acc is not None), None, 0, ws, splits, None, 0, 0)
+           bias, rowadd, group, act, int(acc is not None), None, 0, ws, splits, None, 0, 0, None)
     return C
 
 
@@ -148,6 +148,15 @@ def test_gemm_epilogue_multiplier(M, N, K, splits):
             ref = torch.empty(M, N, device='cuda', dtype=dt)
             L.call('vqa_relu_bwd', L.dt(ref), raw, y, None, M * N, ref, act)
             assert torch.equal(got, ref)
+    # emode 32 + act: both outputs of vqa_hadamard_bwd from the GEMM that forms its incoming gradient
+    for act in (1, 3):
+        fv, fq = torch.randn(M, N, device='cuda'), torch.randn(M, N, device='cuda')
+        raw = ops.gemm(A, B, splits=splits)
+        c2 = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+        got = ops.gemm(A, B, splits=splits, out_dtype=torch.bfloat16, c2=c2, emul=fv, emul2=fq, emode=32 + act)
+        r1, r2 = torch.empty_like(c2), torch.empty_like(c2)
+        L.call('vqa_hadamard_bwd', L.BF16, raw, fv, fq, None, M * N, r1, r2, act)
+        assert torch.equal(got, r1) and torch.equal(c2, r2)
     with pytest.raises(L.VqaHipError):
         ops.gemm(A, B, emul=other, emode=1)                          # emode 1 needs the bf16 copy
     with pytest.raises(L.VqaHipError):

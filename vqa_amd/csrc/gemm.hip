@@ -35,7 +35,11 @@ struct GemmArgs {
     // stays x (vqa_model.py:97-99: C = relu(W_q q + b), C2 = its Hadamard product with the image projection);
     // emode 16 + act: C = x * act'(emul), act' from the activation's OUTPUT (the backward of vqa_model.py:101: the
     // gradient w.r.t. relu's input from the GEMM that forms the gradient w.r.t. its output).
+    // emode 32 + act (emul2 required, same ldm): the backward of the Hadamard product of two activated projections
+    // (vqa_model.py:95-99) in the GEMM that forms its incoming gradient x: C = x * emul2 * act'(emul),
+    // C2 = bf16(x * emul * act'(emul2)) - vqa_hadamard_bwd without a mask (emul = fv, emul2 = fq: C = dpre_v, C2 = dpre_q).
     const float* emul; int ldm; int emode;
+    const float* emul2;
 };
 
 template <typename T>
@@ -73,7 +77,7 @@ __device__ __forceinline__ float epilogue_store(const GemmArgs& g, TC* C, int m,
             if (RICH) { if (g.act == 1 || g.act == 3) x = act_apply(x, g.act); }
             else if (g.act == 1) x = fmaxf(x, 0.f);
             if (g.accumulate) x += to_f32(C[(long)m * g.ldc + ne]);
-            if (g.emode >= 16) x *= act_grad(g.emul[(long)m * g.ldm + ne], g.emode - 16);
+            if (g.emode >= 16 && g.emode < 32) x *= act_grad(g.emul[(long)m * g.ldm + ne], g.emode - 16);
             if (RICH && g.act == 2) {              // the arithmetic of bce_partial (misc.hip), element for element
                 const float t = g.target ? g.target[(long)m * g.ldt + ne] : 0.f;
                 const float ex = __expf(-fabsf(x));
@@ -85,7 +89,15 @@ __device__ __forceinline__ float epilogue_store(const GemmArgs& g, TC* C, int m,
     }
     float v2[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v2[e] = (g.emode == 1 && n + e < g.N) ? v[e] * g.emul[(long)m * g.ldm + n + e] : v[e];
+    for (int e = 0; e < 4; ++e) {
+        v2[e] = v[e];
+        if (g.emode == 1 && n + e < g.N) v2[e] = v[e] * g.emul[(long)m * g.ldm + n + e];
+        if (g.emode >= 32 && n + e < g.N) {
+            const float e1 = g.emul[(long)m * g.ldm + n + e], e2 = g.emul2[(long)m * g.ldm + n + e];
+            v2[e] = v[e] * e1 * act_grad(e2, g.emode - 32);
+            v[e] = v[e] * e2 * act_grad(e1, g.emode - 32);
+        }
+    }
     if (vec_ok && n + 3 < g.N) {
         store_vec4<TC>(C + (long)m * g.ldc + n, v);
         if (g.C2) store_vec4<bf16>(g.C2 + (long)m * g.ldc2 + n, v2);
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += to_f32(C[(long)m * g.ldc + n + e]);
                     }
-                    if (g.emode >= 16) {
+                    if (g.emode >= 16 && g.emode < 32) {
                         const float* em = g.emul + (long)m * g.ldm + n;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] *= act_grad(em[e], g.emode - 16);
@@ -416,7 +428,20 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmArgs g) {
                 const float4 t = *reinterpret_cast<const float4*>(ew + row * EROW + c * 16);
                 const int m = mb + row;
                 if (m < g.M) {
-                    const float o[4] = {t.x, t.y, t.z, t.w};
+                    float o[4] = {t.x, t.y, t.z, t.w};
+                    if (g.emode >= 32) {        // (the raw x went through LDS: both products are formed here)
+                        const float* e1 = g.emul + (long)m * g.ldm + nb + c * 4;
+                        const float* e2 = g.emul2 + (long)m * g.ldm + nb + c * 4;
+                        float o2[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o2[e] = o[e] * e1[e] * act_grad(e2[e], g.emode - 32);
+                            o[e] = o[e] * e2[e] * act_grad(e1[e], g.emode - 32);
+                        }
+                        store_vec4<TC>(C + (long)m * g.ldc + nb + c * 4, o);
+                        store_vec4<bf16>(g.C2 + (long)m * g.ldc2 + nb + c * 4, o2);
+                        continue;
+                    }
                     store_vec4<TC>(C + (long)m * g.ldc + nb + c * 4, o);
                     if (g.C2) {
                         if (g.emode == 1) {
@@ -476,11 +501,18 @@ __global__ void gemm_splitk_reduce(GemmArgs g, int splits) {
             if (g.rowadd) x[e] += g.rowadd[(m / g.rowadd_group) * g.N + n + e];
             if (g.act == 1 || g.act == 3) x[e] = act_apply(x[e], g.act);
             if (g.accumulate) x[e] += to_f32(C[m * g.ldc + n + e]);
-            if (g.emode >= 16) x[e] *= act_grad(g.emul[m * g.ldm + n + e], g.emode - 16);
+            if (g.emode >= 16 && g.emode < 32) x[e] *= act_grad(g.emul[m * g.ldm + n + e], g.emode - 16);
         }
         float x2[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) x2[e] = g.emode == 1 ? x[e] * g.emul[m * g.ldm + n + e] : x[e];
+        for (int e = 0; e < V; ++e) {
+            x2[e] = g.emode == 1 ? x[e] * g.emul[m * g.ldm + n + e] : x[e];
+            if (g.emode >= 32) {
+                const float e1 = g.emul[m * g.ldm + n + e], e2 = g.emul2[m * g.ldm + n + e];
+                x2[e] = x[e] * e1 * act_grad(e2, g.emode - 32);
+                x[e] = x[e] * e2 * act_grad(e1, g.emode - 32);
+            }
+        }
         if constexpr (VEC4) {
             if constexpr (sizeof(TC) == 4) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + m * g.ldc + n) = make_float4(x[0], x[1], x[2], x[3]);
@@ -561,10 +593,14 @@ int launch(hipStream_t s, int trans, const GemmArgs& g, int splits) {
 extern "C" int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K, const void* A, int lda,
                         const void* B, int ldb, void* C, int ldc, int c_dtype, const float* bias,
                         const float* rowadd, int rowadd_group, int act, int accumulate, void* C2, int ldc2,
-                        float* splitk_ws, int splits, const float* emul, int ldm, int emode) {
+                        float* splitk_ws, int splits, const float* emul, int ldm, int emode, const float* emul2) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return VQA_ERR_ARG;
-    if (emode != 0 && emode != 1 && emode != 16 + VQA_ACT_RELU && emode != 16 + VQA_ACT_SELU) return VQA_ERR_ARG;
-    if ((emode != 0) != (emul != nullptr) || (emode && ldm < N) || (emode == 1 && !C2)) return VQA_ERR_ARG;
+    if (emode != 0 && emode != 1 && emode != 16 + VQA_ACT_RELU && emode != 16 + VQA_ACT_SELU &&
+        emode != 32 + VQA_ACT_RELU && emode != 32 + VQA_ACT_SELU)
+        return VQA_ERR_ARG;
+    if ((emode != 0) != (emul != nullptr) || (emode && ldm < N) || ((emode == 1 || emode >= 32) && !C2) ||
+        (emode >= 32) != (emul2 != nullptr))
+        return VQA_ERR_ARG;
     if (rowadd && rowadd_group <= 0) return VQA_ERR_ARG;
     if (splits < 1 || (splits > 1 && !splitk_ws)) return VQA_ERR_ARG;
     const int kc = dtype == VQA_BF16 ? 128 : 16;   // split boundaries on whole pipeline stages
@@ -573,7 +609,7 @@ extern "C" int vqa_gemm(void* stream, int dtype, int trans, int M, int N, int K,
     if (act != 0 && act != 1 && act != 3) return VQA_ERR_ARG;
     GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, bias, rowadd, rowadd_group, act, accumulate,
                static_cast<bf16*>(C2), ldc2, splits > 1 ? splitk_ws : nullptr, kper, nullptr, 0, nullptr, 0, nullptr,
-               emul, ldm, emode};
+               emul, ldm, emode, emul2};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == VQA_F32 && c_dtype == VQA_F32) return launch<float, float>(s, trans, g, splits);
     if (dtype == VQA_BF16 && c_dtype == VQA_F32) return launch<bf16, float>(s, trans, g, splits);
@@ -631,7 +667,7 @@ extern "C" int vqa_fc_bce(void* stream, int dtype, int M, int N, int K, const vo
     }
     if (tiles + M > vqa_fc_bce_part(M, N)) return VQA_ERR_ARG;
     GemmArgs g{M, N, K, A, lda, W, ldw, logits, ldc, nullptr, nullptr, 1, 2, 0, nullptr, 0, nullptr, K,
-               target, ldt, dlogits, ldd, part, nullptr, 0, 0};
+               target, ldt, dlogits, ldd, part, nullptr, 0, 0, nullptr};
     int st;
     if (dtype == VQA_F32) st = launch<float, float>(s, 0, g, 1);
     else if (dtype == VQA_BF16) st = launch<bf16, float>(s, 0, g, 1);

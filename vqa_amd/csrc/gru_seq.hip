@@ -16,7 +16,7 @@ extern "C" int vqa_gru_fwd_steps(void* stream, int dtype, const float* gi, const
         const char* hp_t = static_cast<const char*>(h_t) + (size_t)t * bh * esz;
         char* hn_t = static_cast<char*>(h_t) + (size_t)(t + 1) * bh * esz;
         int st = vqa_gemm(stream, dtype, 0, B, 3 * H, H, hp_t, H, w_hh, ldw, gh, 3 * H, VQA_F32, b_hh, nullptr, 1, 0, 0,
-                          nullptr, 0, splitk_ws, splits, nullptr, 0, 0);
+                          nullptr, 0, splitk_ws, splits, nullptr, 0, 0, nullptr);
         if (st != VQA_OK) return st;
         st = vqa_gru_gate_fwd(stream, dtype, gi + (long)t * B * 3 * H, gh, h_f + t * bh, B, H, h_f + (t + 1) * bh, hn_t,
                               save + (long)t * B * 4 * H);
@@ -43,7 +43,7 @@ extern "C" int vqa_gru_bwd_steps(void* stream, int dtype, const float* dh_last, 
         if (st != VQA_OK) return st;
         if (t > 0) {                                      // dh_{t-1} += dgh_t @ W_hh
             st = vqa_gemm(stream, dtype, 0, B, H, 3 * H, gh_t, 3 * H, w_hh_t, ldw, dprev, H, VQA_F32, nullptr, nullptr, 1,
-                          0, 1, nullptr, 0, splitk_ws, splits, nullptr, 0, 0);
+                          0, 1, nullptr, 0, splitk_ws, splits, nullptr, 0, 0, nullptr);
             if (st != VQA_OK) return st;
         }
         dh = dprev;

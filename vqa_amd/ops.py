@@ -12,11 +12,12 @@ def pad8(n):
 
 
 def gemm(A, B, trans=False, M=None, N=None, K=None, out=None, out_dtype=torch.float32, bias=None, rowadd=None,
-         group=1, act=0, accumulate=False, c2=None, splits=None, emul=None, emode=0):
+         group=1, act=0, accumulate=False, c2=None, splits=None, emul=None, emode=0, emul2=None):
     """NT: out[M,N] = A[M,K] @ B[N,K]^T.   TN (trans=True): out[M,N] = A[K,M]^T @ B[K,N].
     A / B may be row-strided views (stride(1) == 1).  Epilogue: + bias[n] + rowadd[m // group, n], ReLU (act=1),
     accumulate into `out`, optional bf16 copy `c2`; emul / emode: vqa_gemm's epilogue multiplier (emode 1:
-    c2 = bf16(out * emul); emode 16 + act: out *= act'(emul), the derivative from the activation's output)."""
+    c2 = bf16(out * emul); emode 16 + act: out *= act'(emul), the derivative from the activation's output; emode 32 +
+    act: out = x * emul2 * act'(emul), c2 = bf16(x * emul * act'(emul2)), emul2 with emul's row stride)."""
     assert A.stride(1) == 1 and B.stride(1) == 1 and A.dtype == B.dtype
     if trans:
         K = A.shape[0] if K is None else K
@@ -36,7 +37,7 @@ def gemm(A, B, trans=False, M=None, N=None, K=None, out=None, out_dtype=torch.fl
                bytes=float((M * K + N * K) * A.element_size() + M * N * out.element_size()))
     L.call('vqa_gemm', L.dt(A), int(trans), M, N, K, A, A.stride(0), B, B.stride(0), out, out.stride(0), L.dt(out),
            bias, rowadd, group, act, int(accumulate), c2, c2.stride(0) if c2 is not None else 0, ws, splits,
-           emul, emul.stride(0) if emul is not None else 0, emode, tag=tag)
+           emul, emul.stride(0) if emul is not None else 0, emode, emul2, tag=tag)
     return out
 
 

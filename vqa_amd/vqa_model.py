@@ -212,9 +212,13 @@ class _HeadFunction(torch.autograd.Function):
             dm = ops.gemm(dl_t, W_fc_T)                                          # [B,H]
             dpre_last = new(B, H)
             L.call('vqa_relu_bwd', L.dt(dpre_last), dm, m, mask2, B * H, dpre_last, act)
-        dm0 = ops.gemm(dpre_last, W_last_T)
         dpv, dpq = new(B, H), new(B, H)
-        L.call('vqa_hadamard_bwd', L.dt(dpv), dm0, fv, fq, mask1, B * H, dpv, dpq, act)
+        if HEAD_FUSE_ELEMENTWISE and mask1 is None and dtype == torch.bfloat16:
+            # (no dropout) both outputs of the Hadamard product's backward from the GEMM that forms dm0
+            ops.gemm(dpre_last, W_last_T, out=dpv, c2=dpq, emul=fv, emul2=fq, emode=32 + act)
+        else:
+            dm0 = ops.gemm(dpre_last, W_last_T)
+            L.call('vqa_hadamard_bwd', L.dt(dpv), dm0, fv, fq, mask1, B * H, dpv, dpq, act)
         dvhat = ops.gemm(dpv, W_img_T)                                           # [B,D]
         dv = new(B * K, D, dt=torch.float32)
         dpre_a = new(B * K, H)

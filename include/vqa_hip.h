@@ -98,12 +98,19 @@ int vqa_conv3x3_first_wgrad(void* stream, int in_dtype, const void* images, cons
                             int G, int B, int IH, int IW, int OH, int OW, int pad, int R, int CW, int flip);
 /* The same with the BatchNorm-backward apply pass of layer 1 (vqa_bn_bwd, apply = 1, pool = 0) folded in: y is the
  * layer's raw conv output, g the gradient w.r.t. its BatchNorm + ReLU output (both NHWC bf16 [B][OH][OW][16]) and
- * scale .. c2 the six [16] coefficient vectors of that pass; dy = scale * ((z > 0 ? g : 0) - c1 - xhat * c2) is formed
- * at the LDS write and never stored (layer 1 has no data gradient: nobody else reads it). */
+ * scale .. c2 the six [16] coefficient vectors of that pass; dy = scale * ((z > 0 ? g : 0) - c1 - xhat * c2) is never
+ * stored (layer 1 has no data gradient: nobody else reads it) and never formed either: the kernel sums x (x) dz,
+ * x (x) y and x over the pixels and combines the three with the coefficients at the end (dy is affine in dz and y).
+ * part = [G][3][16][32] f32 here.  The three sums need only scale and shift (the ReLU mask), so the kernel can run on
+ * a batch slice as soon as that slice's g exists - before c1 and c2, which need every slice, do: with dw == NULL the
+ * slabs stay in `part` (mean, invstd, c1, c2 may then be NULL) and _bn_reduce, given the slabs of all slices as one
+ * [G][3][16][32] array, sums them in fixed order and writes dw (autograd of cnn.py:23, as the calls above). */
 int vqa_conv3x3_first_wgrad_bn(void* stream, int in_dtype, const void* images, const void* y, const void* g,
                                const float* scale, const float* shift, const float* mean, const float* invstd,
                                const float* c1, const float* c2, float* part, float* dw, int G, int B, int IH, int IW,
                                int OH, int OW, int pad, int R, int CW, int flip);
+int vqa_conv3x3_first_wgrad_bn_reduce(void* stream, const float* part, int G, const float* scale, const float* mean,
+                                      const float* invstd, const float* c1, const float* c2, float* dw);
 
 /* Conv2d weight gradient (autograd of cnn.py:23-40): dw [Cout][Cin_real][3][3] f32 = sum over pixels of dy (x) x.
  * `part` is a [G][Cout][9][Cin] f32 workspace (one partial slab per workgroup group, summed in fixed order; with

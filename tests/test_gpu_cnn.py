@@ -125,8 +125,9 @@ def test_first_layer_exact(img_dtype, B, H, W, pad):
 @pytest.mark.parametrize('B,H,W,pad', [(2, 20, 20, 2), (3, 13, 37, 0), (1, 70, 226, 2), (2, 33, 18, 5), (1, 5, 300, 0)])
 def test_first_layer_fused_bn_wgrad(B, H, W, pad):
     """vqa_conv3x3_first_wgrad_bn (BatchNorm-backward apply inside the weight gradient, dy never stored) against the
-    two-kernel path vqa_bn_bwd(apply) -> vqa_conv3x3_first_wgrad on the same inputs, mirrored read included.  The fused
-    kernel regroups the affine terms (scale*dz - (A*y + Bc)), so dy may differ by a bf16 rounding here and there."""
+    two-kernel path vqa_bn_bwd(apply) -> vqa_conv3x3_first_wgrad on the same inputs, mirrored read included, and both
+    against the same gradient in f64 on the CPU.  The fused kernel never rounds a dy to bf16 - it sums x (x) dz, x (x) y
+    and x and combines them at the end (dy is affine in dz and y) - so it is the closer of the two to the f64 result."""
     from vqa_amd import _lib as L, cnn as C
     torch.manual_seed(B + H + W + pad)
     OH, OW = H + 2 * pad - 2, W + 2 * pad - 2
@@ -138,10 +139,30 @@ def test_first_layer_fused_bn_wgrad(B, H, W, pad):
     c1, c2 = (torch.randn(16) * 0.05).cuda(), (torch.randn(16) * 0.05).cuda()
     dy = torch.empty_like(y)
     L.call('vqa_bn_bwd', L.dt(y), 1, y, g, dy, scale, shift, mean, invstd, c1, c2, None, B, OH, OW, 16, 0)
+    # f64 witness: the same mask (the f32 pre-activation's sign), everything after it in double precision
+    yc, gc = y.float().cpu(), g.float().cpu()
+    sc, sh, mu, isd, k1, k2 = (t.cpu() for t in (scale, shift, mean, invstd, c1, c2))
+    dz = torch.where(torch.addcmul(sh, yc, sc) > 0, gc, torch.zeros(())).double()
+    dy64 = sc.double() * (dz - k1.double() - (yc.double() - mu.double()) * isd.double() * k2.double())
     for mirror in (False, True):
         ref = C.first_wgrad(img, dy, pad, mirror=mirror)
         got = C.first_wgrad(img, y, pad, mirror=mirror, bn=(g, scale, shift, mean, invstd, c1, c2))
         assert float((got - ref).norm() / ref.norm()) < 2e-3
+        w64 = torch.zeros(16, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        x64 = img.cpu().bfloat16().double()             # (both kernels multiply with the image rounded to bf16)
+        F.conv2d(x64.flip(-1) if mirror else x64, w64, padding=pad).backward(dy64.permute(0, 3, 1, 2))
+        e_got = float((got.cpu().double() - w64.grad).norm() / w64.grad.norm())
+        e_ref = float((ref.cpu().double() - w64.grad).norm() / w64.grad.norm())
+        print(f'first_wgrad_bn vs f64: fused {e_got:.2e}, two kernels {e_ref:.2e}')
+        assert e_got < 1e-6 and e_got <= e_ref, (e_got, e_ref)
+        # per batch slice (the sums need only scale and shift), slabs combined at the end: the same gradient
+        parts = []
+        for b in range(B):
+            parts.append(torch.empty(C.first_wgrad_rows(1, OH, OW), 3, 16, 32, device='cuda'))
+            assert C.first_wgrad(img[b:b + 1], y[b:b + 1], pad, mirror=mirror, bn=(g[b:b + 1], scale, shift),
+                                 part_out=parts[-1]) is None
+        sl = C.first_wgrad_reduce(torch.cat(parts), scale, mean, invstd, c1, c2)
+        assert float((sl.cpu().double() - w64.grad).norm() / w64.grad.norm()) < 1e-6
 
 
 @pytest.mark.parametrize('prec,tol', [('fp32', 1e-5), ('bf16', 2e-2)])
@@ -444,7 +465,7 @@ def test_encoder_with_one_kernel_gradients_matches_two(streams, monkeypatch):
     """Whole encoder, bf16: cnn.FUSE_DGRAD_WGRAD = 32 (blocks 1 and 2, block 1 in batch slices) vs 0."""
     from vqa_amd import cnn as M, synth
     sd = {k[4:]: v for k, v in synth.state_dict(42, 64, 50, 30).items() if k.startswith('cnn.')}
-    img = synth.images(8, 3, 224).cuda()
+    img = synth.images(3, 8, 224).cuda()              # (seed 3, a batch of 8)
     monkeypatch.setattr(M, 'WGRAD_STREAM', streams)
     monkeypatch.setattr(M, 'BWD_SLICES', 2)
     monkeypatch.setattr(M, 'BWD_SLICE_MIN_MB', 1.0)
@@ -576,18 +597,23 @@ def test_encoder_with_pooled_bn_backward_matches_separate_pass(prec, monkeypatch
                 assert float((a - b).norm() / b.norm()) < (1e-5 if prec == 'fp32' else 1e-2), k
 
 
-@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('prec,first_sliced', [('fp32', False), ('bf16', False), ('bf16', True)])
 @pytest.mark.parametrize('streams', [True, False])
-def test_batch_sliced_backward_matches_whole_batch(prec, streams, monkeypatch):
+def test_batch_sliced_backward_matches_whole_batch(prec, first_sliced, streams, monkeypatch):
     """cnn.BWD_SLICES: the backward of a block in batch slices (apply pass -> weight gradient -> data gradient per
     slice; by default only where a tensor exceeds the Infinity Cache) against the whole-batch form, forced here for
     EVERY block (2 and 4 slices of a batch of 8): data gradients and BatchNorm gradients are the same arithmetic per
-    image, weight gradients and BatchNorm-backward sums differ in fp32 summation order only."""
+    image, weight gradients and BatchNorm-backward sums differ in fp32 summation order only.  first_sliced
+    (cnn.FIRST_WGRAD_SLICED): the first layer's weight gradient too is formed per slice of block 1 - its three sums
+    right behind each slice's data gradient, combined once BatchNorm 1's c1 and c2 exist."""
     from vqa_amd import cnn as M, synth
     sd = {k[4:]: v for k, v in synth.state_dict(42, 64, 50, 30).items() if k.startswith('cnn.')}
-    img = synth.images(8, 3, 224).cuda()
+    img = synth.images(3, 8, 224).cuda()              # (seed 3, a batch of 8)
     monkeypatch.setattr(M, 'WGRAD_STREAM', streams)
     monkeypatch.setattr(M, 'BWD_SLICE_MIN_MB', 0.0)
+    monkeypatch.setattr(M, 'FIRST_WGRAD_SLICED', first_sliced)
+    combined, reduce0 = [], M.first_wgrad_reduce
+    monkeypatch.setattr(M, 'first_wgrad_reduce', lambda part, *a, **k: (combined.append(part.shape[0]), reduce0(part, *a, **k))[1])
     outs = []
     for slices in (1, 2, 4):
         monkeypatch.setattr(M, 'BWD_SLICES', slices)
@@ -600,6 +626,7 @@ def test_batch_sliced_backward_matches_whole_batch(prec, streams, monkeypatch):
         torch.cuda.synchronize()
         outs.append((out.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}))
     assert M._bwd_slices(8, 1e9) == 4 and M._bwd_slices(6, 1e9) == 2
+    assert len(combined) == (2 if first_sliced else 0)          # (the 2- and the 4-slice pass)
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0])
         for k in o[1]:

@@ -333,16 +333,32 @@ def first_fwd(images, w, bias, pad, want_stats, wscale=None, relu=False, mirror=
     return y, stats
 
 
-def first_wgrad(images, dy, pad, out=None, mirror=False, bn=None):
+def first_wgrad_rows(B, OH, OW):
+    """Partial slabs ([3][16][32] f32 each) the fused first-layer weight gradient leaves for B images."""
+    R, CW = pick_first_tile(OH, OW, 384)
+    return min(B * (-(-OH // R)) * (-(-OW // CW)), 256 * (4 - FIRST_RESERVE))
+
+
+def first_wgrad(images, dy, pad, out=None, mirror=False, bn=None, part_out=None):
     """bn = (g, scale, shift, mean, invstd, c1, c2): `dy` is then the layer's raw conv output y and the BatchNorm-
-    backward apply pass runs inside the kernel (vqa_conv3x3_first_wgrad_bn)."""
+    backward apply pass runs inside the kernel (vqa_conv3x3_first_wgrad_bn).
+    part_out ([first_wgrad_rows(B, OH, OW), 3, 16, 32] f32, with bn = (g, scale, shift)): a batch slice - the three sums
+    are left there for first_wgrad_reduce; returns None."""
     B, _, IH, IW = images.shape
     _, OH, OW, _ = dy.shape
     R, CW = pick_first_tile(OH, OW, 384)                      # (wide tiles: long runs of dy; 0.155 -> 0.139 ms)
     tiles = B * (-(-OH // R)) * (-(-OW // CW))
-    # persistent workgroups: what is resident per CU (84 VGPRs -> 5 waves per SIMD; the fused kernel has 112 -> 4)
+    # persistent workgroups: what is resident per CU (84 registers -> 5 waves per SIMD; the fused kernel: 124 -> 4)
     G = min(tiles, 256 * ((4 if bn is not None else 5) - FIRST_RESERVE))
-    part = P.empty((G, 16, 32), torch.float32, dy.device)
+    if part_out is not None:
+        assert tuple(part_out.shape) == (G, 3, 16, 32) and part_out.is_contiguous() and len(bn) == 3
+        tag = lambda: dict(kind='first_wgrad', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
+                           bytes=float(images.numel() * images.element_size() + 2 * dy.numel() * 2))
+        L.call('vqa_conv3x3_first_wgrad_bn', L.dt(images), images, dy, *bn, None, None, None, None, part_out, None, G,
+               B, IH, IW, OH, OW, pad, R, CW, int(mirror), tag=tag)
+        return None
+    # (the fused form leaves three slabs per workgroup: sum x dz, sum x y, sum x - conv_first.hip)
+    part = P.empty((G, 3 if bn is not None else 1, 16, 32), torch.float32, dy.device)
     dw = out if out is not None else P.empty((16, 3, 3, 3), torch.float32, dy.device)
     tag = lambda: dict(kind='first_wgrad', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
                bytes=float(images.numel() * images.element_size() + dy.numel() * 2))
@@ -354,6 +370,14 @@ def first_wgrad(images, dy, pad, out=None, mirror=False, bn=None):
         return dw
     L.call('vqa_conv3x3_first_wgrad', L.dt(images), images, dy, part, dw, G, B, IH, IW, OH, OW, pad, R, CW,
            int(mirror), tag=tag)
+    return dw
+
+
+def first_wgrad_reduce(part, scale, mean, invstd, c1, c2, out=None):
+    """The slabs first_wgrad(part_out=...) left for every batch slice, as one [G, 3, 16, 32] array -> dw [16,3,3,3]."""
+    assert part.dim() == 4 and tuple(part.shape[1:]) == (3, 16, 32) and part.is_contiguous()
+    dw = out if out is not None else P.empty((16, 3, 3, 3), torch.float32, part.device)
+    L.call('vqa_conv3x3_first_wgrad_bn_reduce', part, part.shape[0], scale, mean, invstd, c1, c2, dw)
     return dw
 
 
@@ -393,7 +417,8 @@ def coef_block(scale, shift, mean, invstd):
 
 
 def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, gdst, first=False, wpk_d=None, mirror=False,
-              side=None, in_coeffs=None, part=None, bst=None, defer=None, hold=None):
+              side=None, in_coeffs=None, part=None, bst=None, defer=None, hold=None, first_below=None,
+              first_part=None):
     """d = gradient w.r.t. the block output (NHWC, activation dtype).  gdst = (dw, dgamma, dbeta): where the layer's
     parameter gradients are written (slots of the flat gradient buffer, or of the pass's own gradient block; the conv
     bias feeds a training-mode BatchNorm, so its gradient is identically zero - the reference produces rounding noise
@@ -403,7 +428,10 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, gdst, first=False, wpk_
     part: this block's BatchNorm-backward partial sums, already produced by the data gradient of the block above.
     bst = (y, coef) of the block BELOW: this block's data gradient also produces that block's partial sums (`below`).
     hold (a list, side stream only): the weight gradient is not issued here - a closure that orders the side stream
-    behind the main stream AT THE TIME IT IS CALLED and then issues it is appended instead (see WGRAD_HOLD)."""
+    behind the main stream AT THE TIME IT IS CALLED and then issues it is appended instead (see WGRAD_HOLD).
+    first_below = (images, pad, mirror, sink): the block below is the first layer; when this block runs in batch slices
+    the three sums of that layer's weight gradient are formed per slice, right behind the data gradient that wrote the
+    slice's d (FIRST_WGRAD_SLICED), and the slabs are appended to `sink`.  first_part: those slabs, for the first layer."""
     x, y, scale, shift, mean, invstd = saved
     dev = y.device
     B, H, W, C = y.shape
@@ -425,7 +453,9 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, gdst, first=False, wpk_
     if first and pool == 0 and not need_dx and FUSE_FIRST_BN:
         # layer 1: nobody but its weight gradient reads dy - the apply pass runs inside that kernel, dy is never stored
         bn = (d, scale, shift, mean, invstd, c1, c2)
-        if side is None or FIRST_WGRAD_MAIN:
+        if first_part is not None:
+            first_wgrad_reduce(first_part, scale, mean, invstd, c1, c2, out=dw_out)
+        elif side is None or FIRST_WGRAD_MAIN:
             first_wgrad(x, y, pad, out=dw_out, mirror=mirror, bn=bn)
         else:
             P.stream_wait(side, cur)
@@ -451,6 +481,11 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, gdst, first=False, wpk_
         below = P.empty((S * gd, cin, 2), torch.float32, dev) if bst else None
         gw = gd if both else wgrad_rows(x[:Bs], dys[:Bs], pad)
         part_w = P.empty((S * gw, C, 9, cin), torch.float32, dev)
+        fpart = None
+        if first_below is not None and both and FIRST_WGRAD_SLICED and FUSE_FIRST_BN:
+            g1 = first_wgrad_rows(Bs, IH, IW)
+            fpart = P.empty((S * g1, 3, 16, 32), torch.float32, dev)
+            first_below[3].append(fpart)
         for si in range(S):
             sl = slice(si * Bs, (si + 1) * Bs)
             tag = lambda sl=sl: dict(kind='apply', shape=f'{H}x{W}x{C}', flops=0.0,
@@ -460,6 +495,11 @@ def block_bwd(d, saved, w, cin_real, pad, pool, need_dx, gdst, first=False, wpk_
             if both:        # one pass over (dy, x): the slabs come out of the data gradient's kernel
                 conv_dgrad_wgrad(dys[sl], wd, cin, (bst[0][sl], bst[1]), cin_real, out=dx[sl],
                                  stats_out=below[si * gd:(si + 1) * gd], part_out=part_w[si * gw:(si + 1) * gw])
+                if fpart is not None:
+                    # the first layer's x (x) dz, x (x) y and x sums of this slice, while its d and y are still in the
+                    # Infinity Cache (scale, shift: rows 0 and 1 of the coefficient block of the layer below)
+                    first_wgrad(first_below[0][sl], bst[0][sl], first_below[1], mirror=first_below[2],
+                                bn=(dx[sl], bst[1][0], bst[1][1]), part_out=fpart[si * g1:(si + 1) * g1])
                 continue
             if side is not None:
                 P.stream_wait(side, cur)
@@ -612,6 +652,14 @@ BWD_SLICES = int(os.environ.get('VQA_BWD_SLICES', '0'))
 # and the 65 us it adds to the data gradient are on the critical chain.
 FUSE_DGRAD_WGRAD = int(os.environ.get('VQA_FUSE_DGRAD_WGRAD', '16'))
 BWD_SLICE_MIN_MB = float(os.environ.get('VQA_BWD_SLICE_MIN_MB', '300'))
+# VQA_FIRST_WGRAD_SLICED=1: the first layer's weight gradient per batch slice of block 1's backward
+# (vqa_conv3x3_first_wgrad_bn with dw = NULL, then _bn_reduce) - the kernel that runs last, reading y1 and d1 (418 MB
+# each) back from HBM, runs right behind the data gradient that wrote the slice's d1 instead (its sums need only
+# BatchNorm 1's scale and shift; c1 and c2, which need every slice, enter when the slabs are combined).  Off: measured
+# on one box, 150-step runs: 3.953 / 3.961 / 3.957 against 3.960 / 3.955 / 3.961 ms/step with the default two slices
+# (a 128-image slice's traffic, 620 MB, is 2.4 x the Infinity Cache: little of d1 and y1 is still there), and SLOWER
+# with four (3.999 against 3.975-3.986; eight: 4.12): what the cache returns, the smaller launches take.
+FIRST_WGRAD_SLICED = os.environ.get('VQA_FIRST_WGRAD_SLICED', '0') != '0'
 WGRAD_RESERVE = int(os.environ.get('VQA_WGRAD_RESERVE', '0'))
 # the deep weight gradient's four-output-fragment form (read by the library from the same variable; measured slower:
 # one wave per SIMD - conv.hip)
@@ -660,7 +708,7 @@ def _knobs():
     return (WGRAD_STREAM, FUSE_BN_FWD, FUSE_BN_BWD, FUSE_FIRST_BN, FUSE_POOL_BWD, DEFER_WGRAD_REDUCE, BWD_SLICES,
             BWD_SLICE_MIN_MB, WGRAD_RESERVE, FIRST_WGRAD_MAIN, FIRST_RESERVE, WGRAD_HOLD_FROM, WGRAD_RELEASE_AT,
             FUSE_DGRAD_WGRAD,
-            WGRAD_COF4, WGRAD_PAIR)
+            WGRAD_COF4, WGRAD_PAIR, FIRST_WGRAD_SLICED)
 
 
 def out_regions(size, padding):
@@ -738,6 +786,7 @@ def _train_backward(dout, saved, ysels, wd, meta, gdsts, dtype, first, mirror):
     part = None
     deferred = [] if DEFER_WGRAD_REDUCE else None      # weight-gradient slabs, reduced by one launch at the end
     held = []
+    fsink = []                                          # the first layer's weight-gradient slabs, formed per slice of block 1
     for li in range(9, -1, -1):
         pad, pool, fused_in = meta[li]
         # the block below has no pool: this block's data gradient can also do its BatchNorm-backward reduction
@@ -753,7 +802,9 @@ def _train_backward(dout, saved, ysels, wd, meta, gdsts, dtype, first, mirror):
         d, part = block_bwd(d, saved[6 * li: 6 * li + 6], None, CHANNELS[li], pad, pool, li > 0, (g[0], g[2], g[3]),
                             first=first and li == 0, wpk_d=wd[li], mirror=mirror and li == 0, side=side,
                             in_coeffs=in_coeffs, part=part, bst=bst, defer=deferred,
-                            hold=held if (side is not None and 0 < WGRAD_HOLD_FROM <= li) else None)
+                            hold=held if (side is not None and 0 < WGRAD_HOLD_FROM <= li) else None,
+                            first_below=(saved[0], meta[0][0], mirror, fsink) if (first and li == 1) else None,
+                            first_part=fsink[0] if (li == 0 and fsink) else None)
         if held and li <= WGRAD_RELEASE_AT:
             for fn in held:
                 fn()

@@ -5,9 +5,9 @@
 //   conv3x3_first_fwd    y[B][OH][OW][16] (bf16, NHWC) = conv(images) + bias, with the BatchNorm partial statistics;
 //                        LDS patch pixel-interleaved (4 bf16 per pixel), three 16x16x16 MFMAs per 16 output pixels
 //   conv3x3_first_wgrad  dW[16][3][3][3] = sum over pixels of dy (x) image patch, persistent workgroups over tiles;
-//                        LDS patch as 3 planes of (R+2) x (CW+2) bf16, fragment elements gathered with 2-byte LDS
-//                        reads (k-major gather offsets are per-lane constants), one 16x16x32 MFMA per 32 pixels
-//   ..._first_wgrad_bn   the same from (y, g): the BatchNorm-backward apply pass of layer 1 folded into the dy staging
+//                        the same pixel-interleaved LDS patch; both operands by transposing LDS reads (the reduction
+//                        runs over pixels), columns n = 4 tap + c: three 16x16x32 MFMAs per 32 pixels
+//   ..._first_wgrad_bn   the same from (y, g): the BatchNorm-backward apply pass of layer 1 folded in by linearity
 // HBM-bound: bytes = |images| + |y|.
 #include "common.h"
 #include <type_traits>
@@ -34,8 +34,7 @@ struct FirstArgs {
     int rev;             // walk the tiles back to front (unit_walk, common.h)
 };
 
-constexpr int PMAX = 384;                       // host bound on (R+2)*(CW+2)
-constexpr int NIV = (3 * PMAX + 255) / 256;     // image elements per thread per tile
+constexpr int PMAX = 384;                       // weight gradient: host bound on (R+2)*(CW+2)
 
 // One image element through the buffer resource: an offset at or beyond the buffer's size returns 0 (the zero padding).
 template <typename TI> __device__ __forceinline__ float buffer_ld_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off);
@@ -54,56 +53,6 @@ template <> __device__ __forceinline__ float buffer_ld_f32<float>(__amdgpu_buffe
 // Both kernels are persistent: workgroup g walks the (image, tile) pairs t = g, g + G, ...; what does not depend on the
 // tile is computed once per workgroup (a wave64 VALU instruction costs its SIMD 4 cycles, and per-tile index
 // arithmetic is what these HBM-bound kernels spend their time on otherwise).
-struct PatchPlan {           // per thread: the NIV patch elements (c, py, px) it stages
-    int rel[NIV];            // BYTES from the tile's top-left input pixel: (c*IH*IW + (py-pad)*IW + (px-pad)) * sizeof(TI)
-    int pyx[NIV];            // (py-pad) << 16 | (px-pad+64); "never inside" rows for elements beyond the patch
-};
-
-template <typename TI>
-__device__ __forceinline__ void plan_patch(const FirstArgs& a, int PW, int PP, PatchPlan& pl) {
-    const int tid = threadIdx.x;
-    const float inv_pp = 1.0f / PP;
-#pragma unroll
-    for (int j = 0; j < NIV; ++j) {
-        const int i = tid + j * 256;
-        const int c = fastdiv(i, PP, inv_pp), rem = i - c * PP;
-        const int py = fastdiv(rem, PW, a.inv_pw), px = rem - py * PW;
-        pl.rel[j] = (c * a.IH * a.IW + (py - a.pad) * a.IW + (a.flip ? a.pad - px : px - a.pad)) * (int)sizeof(TI);
-        pl.pyx[j] = ((c < 3 ? py - a.pad : -0x4000) << 16) | (px - a.pad + 64);
-    }
-}
-
-// Branch-free fetch of tile (b, oy0, ox0): all NIV loads in flight together; out-of-image elements are requested at the
-// buffer's size, which the hardware answers with 0.
-template <typename TI>
-__device__ __forceinline__ void fetch_patch(const FirstArgs& a, __amdgpu_buffer_rsrc_t ibuf, unsigned ibytes,
-                                            const PatchPlan& pl, int b, int oy0, int ox0, float (&v)[NIV]) {
-    // (mirrored column: in range iff the column is)
-    const unsigned org = (unsigned)((b * 3 * a.IH + oy0) * a.IW + (a.flip ? a.IW - 1 - ox0 : ox0)) * (unsigned)sizeof(TI);
-#pragma unroll
-    for (int j = 0; j < NIV; ++j) {
-        const bool ok = (unsigned)(oy0 + (pl.pyx[j] >> 16)) < (unsigned)a.IH &&
-                        (unsigned)(ox0 - 64 + (pl.pyx[j] & 0xFFFF)) < (unsigned)a.IW;
-        v[j] = buffer_ld_f32<TI>(ibuf, ok ? org + (unsigned)pl.rel[j] : ibytes);
-    }
-}
-
-__device__ __forceinline__ void stash_patch(unsigned char* patch, int n, const float (&v)[NIV]) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < NIV; ++j) {
-        const int i = tid + j * 256;
-        const bf16 t = (bf16)v[j];
-        if (i < n) reinterpret_cast<bf16*>(patch)[i] = t;
-    }
-}
-
-// k = 8q + j  ->  element offset of (c, ky, kx) inside the patch; padded k (>= 27) reads element 0 (its weight is 0)
-__device__ __forceinline__ int gather_off(int k, int PW, int PP) {
-    if (k >= 27) return 0;
-    const int c = k / 9, t = k - c * 9;
-    return c * PP + (t / 3) * PW + (t % 3);
-}
 
 // ---- forward: pixel-interleaved patch.  LDS holds the (R+2) x (CW+2) input pixels as 4 bf16 each (3 channels and a
 // zero), 8 bytes per pixel.  The K = 16 values of ONE kernel row ky - k = 4*kx + c with kx, c in 0..3, where kx = 3 and
@@ -291,36 +240,42 @@ __global__ __launch_bounds__(256) void conv3x3_first_fwd(FirstArgs a) {
 // (dy fragment by the transposing LDS read), D cols = k index (two 16-column tiles cover k = 0..31), MFMA K = 32
 // pixels with the k <-> pixel map of conv.hip's wgrad: lane group q, element 4h+e <-> pixel ks + 16h + 4q + e.
 // The pixel -> patch offset of every K element is a per-workgroup LDS table (no division in the loop).
-// FUSED: the BatchNorm-backward apply pass of layer 1 happens here, at the LDS write of the dy tile - layer 1 has no data
-// gradient, so its dy was written (418 MB at B = 256) only to be read back by this kernel.
+// FUSED: the BatchNorm-backward apply pass of layer 1 happens here - layer 1 has no data gradient, so its dy was written
+// (418 MB at B = 256) only to be read back by this kernel - and by LINEARITY: with dz = z > 0 ? g : 0,
+//   dy = scale * dz - (A * y + Bc)   =>   dW[c][k] = scale_c * sum(x_k dz_c) - A_c * sum(x_k y_c) - Bc_c * sum(x_k),
+// so the tile's dz and its raw y go to LDS side by side and the MFMAs form the three sums (the third against a column of
+// ones over the pixels inside the image); first_wgrad_reduce_bn combines them.  What is left for the VALU is the ReLU
+// mask - the per-element affine arithmetic in front of the LDS write was 44 of this kernel's 210 us (a build without it
+// ran at the 167 us its 913 MB take), and each dy was rounded to bf16 before it met its x.
 template <typename TI, bool FUSED>
 __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int PW = a.CW + 2, PP = (a.R + 2) * PW, MT = a.R * a.CW;
     const int MTP = (MT + 31) / 32 * 32;
-    unsigned char* patch = smem;
-    unsigned char* dyl = smem + (3 * PP * 2 + 15) / 16 * 16;      // [MTP pixels][16 co] bf16, 32 bytes per pixel
-    short* ptab = reinterpret_cast<short*>(dyl + MTP * 32);       // [MTP] byte offset of pixel m inside a patch plane
-    float* coef = reinterpret_cast<float*>(dyl + MTP * 32 + ((MTP * 2 + 15) / 16) * 16);   // FUSED: [4][16]
+    unsigned char* patch = smem;                                  // [PP + 1 pixels][4] bf16: 3 channels and a zero
+    unsigned char* dyl = smem + ((PP + 1) * 8 + 15) / 16 * 16;    // [MTP pixels][16 co] bf16, 32 bytes per pixel
+    short* ptab = reinterpret_cast<short*>(dyl + MTP * 32);       // [MTP] byte offset of tile pixel m inside the patch
+    float* coef = reinterpret_cast<float*>(dyl + MTP * 32 + ((MTP * 2 + 15) / 16) * 16);   // FUSED: [2][16] scale, shift
+    unsigned char* yl = reinterpret_cast<unsigned char*>(coef + 6 * 16);  // FUSED: the raw y tile, laid out as dyl
+    bf16* vl = reinterpret_cast<bf16*>(yl + MTP * 32);                   // FUSED: [MTP] 1 = tile pixel inside the image
+    constexpr int NS = FUSED ? 3 : 1;                            // A operands: dz (or dy), y, ones
+    constexpr int NA = NS * 3;                                   // x 3 column tiles: taps 0-3, 4-7, 8
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4, rq = r >> 2, p = r & 3;
-    const unsigned ibytes = (unsigned)a.B * 3 * a.IH * a.IW * (unsigned)sizeof(TI);      // (launcher: both < 4 GiB)
-    const unsigned dbytes = (unsigned)a.B * a.OH * a.OW * 32u;
+    const unsigned plane = (unsigned)a.IH * a.IW * (unsigned)sizeof(TI);
+    const unsigned ibytes = (unsigned)a.B * 3 * plane;                                   // (launcher: < 2 GiB)
+    const unsigned dbytes = (unsigned)a.B * a.OH * a.OW * 32u;                           // (launcher: < 4 GiB)
     const __amdgpu_buffer_rsrc_t ibuf = buffer_of(a.img, ibytes), dbuf = buffer_of(a.y, dbytes);
     const __amdgpu_buffer_rsrc_t gbuf = buffer_of(FUSED ? a.g : a.y, dbytes);
     const int tiles = a.tiles_x * a.tiles_y, total = tiles * a.B;
     if ((int)blockIdx.x >= total) return;
     if (FUSED && tid < 16) {
-        // dy = scale * (dz - c1 - (y - mean) * invstd * c2)  =  scale * dz - (A * y + Bc),  dz = z > 0 ? g : 0
-        const float sc = a.bn_scale[tid], A = sc * a.bn_invstd[tid] * a.bn_c2[tid];
-        coef[tid] = sc;
+        coef[tid] = a.bn_scale[tid];                              // z = scale * y + shift: the layer's pre-activation
         coef[16 + tid] = a.bn_shift[tid];
-        coef[32 + tid] = A;
-        coef[48 + tid] = sc * a.bn_c1[tid] - A * a.bn_mean[tid];
     }
 
-    PatchPlan pl;
-    plan_patch<TI>(a, PW, PP, pl);
+    PixelPlan pl;
+    plan_pixels<TI>(a, PW, PP, pl);
     // dy vectors of this thread: pixel m = i >> 1, half vv = i & 1
     int drel[2], drc[2];
 #pragma unroll
@@ -333,10 +288,21 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
     if (tid < MTP) {
         const int m = tid < MT ? tid : 0;                         // dy rows beyond the tile are zero: any finite value
         const int pr = fastdiv(m, a.CW, a.inv_cw);
-        ptab[tid] = (short)((pr * PW + (m - pr * a.CW)) * 2);
+        ptab[tid] = (short)((pr * PW + (m - pr * a.CW)) * 8);
     }
-    const int koff0 = gather_off(r, PW, PP) * 2, koff1 = gather_off(16 + r, PW, PP) * 2;   // k = r and k = 16 + r
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    // The x operand, B[pixel][n]: column tile j holds taps 4j .. 4j+3 with the 4 channel slots of each, n = 4 tap + c.
+    // For a transposing read lane (rq, p) hands in the 8 bytes of pixel m0 + rq under tap 4j + p and lane r receives
+    // column r of the 4 pixels m0 .. m0+3: (tap 4j + (r >> 2), channel r & 3).  Taps beyond 8 re-read tap 8 and channel
+    // slot 3 is the zero: both land in columns nobody stores.
+    int toff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int tap = 4 * j + p < 8 ? 4 * j + p : 8;
+        toff[j] = ((tap / 3) * PW + tap % 3) * 8;
+    }
+    f32x4 acc[NA];
+#pragma unroll
+    for (int n = 0; n < NA; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto tile_org = [&](int t, int& b, int& oy0, int& ox0) {
         b = fastdiv(t, tiles, a.inv_tiles);
@@ -344,13 +310,13 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
         oy0 = ty * a.R;
         ox0 = (tl - ty * a.tiles_x) * a.CW;
     };
-    float pv[NIV];
+    float pv[NPX][3];
     uint4 dv[2], gv[2];
     unsigned okbits = 0;
     auto fetch = [&](int t) {
         int b, oy0, ox0;
         tile_org(t, b, oy0, ox0);
-        fetch_patch<TI>(a, ibuf, ibytes, pl, b, oy0, ox0, pv);
+        fetch_pixels<TI>(a, ibuf, ibytes, plane, pl, b, oy0, ox0, pv);
         const unsigned dorg = (unsigned)((b * a.OH + oy0) * a.OW + ox0) * 32u;
         okbits = 0;
 #pragma unroll
@@ -363,76 +329,90 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad(FirstArgs a) {
             }
         }
     };
-    // FUSED: (y, g) -> dy of 8 channels (thread's half vv = tid & 1) in packed f32x2 arithmetic; the coefficients are
-    // read from LDS (the kernel has no registers to spare for 32 of them)
-    auto bn_apply = [&](const uint4& yv, const uint4& gq, bool ok) {
+    // FUSED: (y, g) -> dz of 8 channels (thread's half vv = tid & 1): g where the pre-activation is positive.  Outside
+    // the image both loads return zeros, so dz = 0 there without a test; the coefficients are read from LDS (the kernel
+    // has no registers to spare for 16 of them)
+    auto relu_mask = [&](const uint4& yv, const uint4& gq) {
         const unsigned yw[4] = {yv.x, yv.y, yv.z, yv.w}, gw[4] = {gq.x, gq.y, gq.z, gq.w};
         const f32x2* c2v = reinterpret_cast<const f32x2*>(coef + (tid & 1) * 8);
         unsigned ow[4];
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const f32x2 y = {__uint_as_float(yw[h] << 16), __uint_as_float(yw[h] & 0xFFFF0000u)};
-            const f32x2 g = {__uint_as_float(gw[h] << 16), __uint_as_float(gw[h] & 0xFFFF0000u)};
-            const f32x2 sc = c2v[h], sh = c2v[8 + h], A = c2v[16 + h], Bc = c2v[24 + h];
-            const f32x2 z = __builtin_elementwise_fma(y, sc, sh);
-            const f32x2 t = sc * g;
-            const f32x2 lin = __builtin_elementwise_fma(A, y, Bc);
-            f32x2 o = {(z.x > 0.f ? t.x : 0.f), (z.y > 0.f ? t.y : 0.f)};
-            o = o - lin;
-            typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-            const bf16x2_t ob = {(bf16)o.x, (bf16)o.y};
-            ow[h] = ok ? __builtin_bit_cast(unsigned, ob) : 0u;
+            const f32x2 z = __builtin_elementwise_fma(y, c2v[h], c2v[8 + h]);
+            const unsigned lo = z.x > 0.f ? gw[h] : 0u, hi = z.y > 0.f ? gw[h] : 0u;
+            ow[h] = (lo & 0xFFFFu) | (hi & 0xFFFF0000u);
         }
         return make_uint4(ow[0], ow[1], ow[2], ow[3]);
     };
     const UnitWalk uw = unit_walk(blockIdx.x, gridDim.x, total, a.rev);
     fetch(uw.unit(uw.first));
     __syncthreads();                                              // (coef)
+    typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4;
     for (int t = uw.first; t < uw.end; t += uw.step) {
-        stash_patch(patch, 3 * PP, pv);
+        stash_pixels(patch, PP, pv);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = tid + j * 256;
-            const uint4 tv = FUSED ? bn_apply(dv[j], gv[j], (okbits >> j) & 1) : dv[j];
-            if (i < MTP * 2) *reinterpret_cast<uint4*>(dyl + i * 16) = tv;
+            const uint4 tv = FUSED ? relu_mask(dv[j], gv[j]) : dv[j];
+            if (i < MTP * 2) {
+                *reinterpret_cast<uint4*>(dyl + i * 16) = tv;
+                if (FUSED) {
+                    *reinterpret_cast<uint4*>(yl + i * 16) = dv[j];
+                    if ((tid & 1) == 0) vl[i >> 1] = (bf16)(((okbits >> j) & 1) ? 1.f : 0.f);
+                }
+            }
         }
         __syncthreads();
         if (t + uw.step < uw.end) fetch(uw.unit(t + uw.step));
         for (int ks = wave * 32; ks < MTP; ks += 128) {
-            bf16x8 fa, fb0, fb1;
+            bf16x8 fa[NS], fb[3];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int m0 = ks + h * 16 + q * 4;               // first of the 4 pixels of K elements 4h..4h+3
-                bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(dyl + (m0 + rq) * 32 + 4 * p * 2));
-                const short4 po = *reinterpret_cast<const short4*>(ptab + m0);
-                const int pof[4] = {po.x, po.y, po.z, po.w};
+                bf16x4 va[NS], vx[3];
+                va[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(dyl + (m0 + rq) * 32 + 4 * p * 2));
+                if (FUSED) {
+                    va[1 % NS] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(yl + (m0 + rq) * 32 + 4 * p * 2));
+                    va[2 % NS] = *reinterpret_cast<const bf16x4*>(vl + m0);      // every row of the ones operand alike
+                }
+                const unsigned char* px = patch + ptab[m0 + rq];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) vx[j] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(px + toff[j]));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    fa[4 * h + e] = v[e];
-                    fb0[4 * h + e] = *reinterpret_cast<const bf16*>(patch + pof[e] + koff0);
-                    fb1[4 * h + e] = *reinterpret_cast<const bf16*>(patch + pof[e] + koff1);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) fa[s][4 * h + e] = va[s][e];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) fb[j][4 * h + e] = vx[j][e];
                 }
             }
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb1, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[s * 3 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s], fb[j], acc[s * 3 + j], 0, 0, 0);
         }
         __syncthreads();                                          // fragment reads done before the next stash
     }
-    // combine the 4 waves (fixed order) and write this workgroup's partial slab [16 co][32 k]
-    float* red = reinterpret_cast<float*>(smem);                  // [3 waves][2][64 lanes][4]
+    // combine the 4 waves (fixed order) and write this workgroup's partial slabs [NS][16 co][32 k]
+    float* red = reinterpret_cast<float*>(smem);                  // [3 waves][NA][64 lanes][4]
     if (wave > 0) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) *reinterpret_cast<f32x4*>(red + (((wave - 1) * 2 + n) * 64 + lane) * 4) = acc[n];
+        for (int n = 0; n < NA; ++n) *reinterpret_cast<f32x4*>(red + (((wave - 1) * NA + n) * 64 + lane) * 4) = acc[n];
     }
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            for (int w = 0; w < 3; ++w) acc[n] += *reinterpret_cast<const f32x4*>(red + ((w * 2 + n) * 64 + lane) * 4);
+        for (int n = 0; n < NA; ++n) {
+            for (int w = 0; w < 3; ++w) acc[n] += *reinterpret_cast<const f32x4*>(red + ((w * NA + n) * 64 + lane) * 4);
+            // D row = co = 4q+e; D col r of column tile j = n % 3: tap 4j + (r >> 2), channel r & 3 -> k = 9 c + tap
+            const int tap = 4 * (n % 3) + rq, c = p;
+            if (tap < 9 && c < 3) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)                            // D row = co = 4q+e, D col = k = 16n + r
-                a.stats[((long)blockIdx.x * 16 + q * 4 + e) * 32 + n * 16 + r] = acc[n][e];
+                for (int e = 0; e < 4; ++e)
+                    a.stats[(((long)blockIdx.x * NS + n / 3) * 16 + q * 4 + e) * 32 + c * 9 + tap] = acc[n][e];
+            }
         }
     }
 }
@@ -446,6 +426,47 @@ __global__ __launch_bounds__(256) void first_wgrad_reduce(const float* part, flo
     for (int g = lane; g < G; g += 64) s += part[((long)g * 16 + co) * 32 + k];
     s = wave_sum(s);
     if (lane == 0) dw[o] = s;
+}
+
+// The fused form's three slabs per workgroup - S1 = sum x dz, S2 = sum x y, S3 = sum x (every row alike) - summed over
+// the workgroups in fixed order (f64) and combined with the BatchNorm-backward coefficients of the apply pass
+// (bn.hip: dy = scale * (dz - c1 - xhat * c2)  =  scale * dz - (A * y + Bc), A = scale * invstd * c2, Bc = scale * c1 -
+// A * mean):  dw[co][k] = scale * S1 - A * S2 - Bc * S3.
+__global__ __launch_bounds__(1024) void first_wgrad_reduce_bn(const float* part, float* dw, int G, const float* scale,
+                                                              const float* mean, const float* invstd, const float* c1,
+                                                              const float* c2) {
+    // One workgroup per output channel: thread = (k, slab lane gl); a wave's load is 2 whole 128-byte rows of a slab
+    // (one wave per output, lanes striding over the slabs, touched a cache line per lane and took 15 us - this kernel
+    // is the last of the backward's chain).  Fixed order: slabs gl, gl + 32, ... per thread, then the 32 lanes in turn.
+    __shared__ double red[3][32][33];
+    const int co = blockIdx.x, k = threadIdx.x & 31, gl = threadIdx.x >> 5;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int g0 = gl; g0 < G; g0 += 32 * 8) {
+        float v[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int g = g0 + 32 * u;
+            const float* p = part + (long)(g < G ? g : 0) * 3 * 512;
+            v[u][0] = p[co * 32 + k];
+            v[u][1] = p[512 + co * 32 + k];
+            v[u][2] = p[1024 + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s[j] += g0 + 32 * u < G ? (double)v[u][j] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) red[j][gl][k] = s[j];
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        double t[3] = {0.0, 0.0, 0.0};
+        for (int l = 0; l < 32; ++l)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) t[j] += red[j][l][k];
+        const float sc = scale[co], A = sc * invstd[co] * c2[co], Bc = sc * c1[co] - A * mean[co];
+        dw[co * 27 + k] = (float)((double)sc * t[0] - (double)A * t[1] - (double)Bc * t[2]);
+    }
 }
 
 bool first_args(FirstArgs& a, int B, int IH, int IW, int OH, int OW, int pad, int R, int CW, int pmax) {
@@ -496,12 +517,16 @@ extern "C" int vqa_conv3x3_first_fwd(void* stream, int in_dtype, const void* ima
 
 static int first_wgrad_launch(void* stream, int in_dtype, FirstArgs& a, float* part, float* dw, int G, int B, int IH,
                               int IW, int OH, int OW, int pad, int R, int CW, bool fused) {
-    if (!a.img || !a.y || !part || !dw || G < 1 || !first_args(a, B, IH, IW, OH, OW, pad, R, CW, PMAX)) return VQA_ERR_ARG;
+    // (dw == NULL, fused form only: the slabs are left in `part` for vqa_conv3x3_first_wgrad_bn_reduce)
+    if (!a.img || !a.y || !part || (!dw && !fused) || G < 1 || !first_args(a, B, IH, IW, OH, OW, pad, R, CW, PMAX))
+        return VQA_ERR_ARG;
     const int MTP = (R * CW + 31) / 32 * 32;
     if (G > a.tiles_x * a.tiles_y * B) return VQA_ERR_ARG;
-    size_t lds = (size_t)(3 * (R + 2) * (CW + 2) * 2 + 15) / 16 * 16 + (size_t)MTP * 32 + (size_t)(MTP * 2 + 15) / 16 * 16 +
+    size_t lds = (size_t)(((R + 2) * (CW + 2) + 1) * 8 + 15) / 16 * 16 + (size_t)MTP * 32 + (size_t)(MTP * 2 + 15) / 16 * 16 +
                  6 * 16 * 4;
-    if (lds < 3 * 2 * 64 * 16) lds = 3 * 2 * 64 * 16;
+    if (fused) lds += (size_t)MTP * 32 + (size_t)(MTP * 2 + 15) / 16 * 16;      // the y tile and the column of ones
+    const size_t red = (size_t)3 * (fused ? 9 : 3) * 64 * 16;                    // the cross-wave combine at the end
+    if (lds < red) lds = red;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (in_dtype != VQA_F16 && in_dtype != VQA_F32 && in_dtype != VQA_BF16) return VQA_ERR_ARG;
 #define GO(F)                                                                                                         \
@@ -512,7 +537,13 @@ static int first_wgrad_launch(void* stream, int in_dtype, FirstArgs& a, float* p
     } while (0)
     if (fused) GO(true); else GO(false);
 #undef GO
-    hipLaunchKernelGGL(first_wgrad_reduce, dim3(108), dim3(256), 0, s, part, dw, G);
+    if (fused && !dw)
+        ;
+    else if (fused)
+        hipLaunchKernelGGL(first_wgrad_reduce_bn, dim3(16), dim3(1024), 0, s, part, dw, G, a.bn_scale, a.bn_mean,
+                           a.bn_invstd, a.bn_c1, a.bn_c2);
+    else
+        hipLaunchKernelGGL(first_wgrad_reduce, dim3(108), dim3(256), 0, s, part, dw, G);
     CHECK_LAUNCH();
     return VQA_OK;
 }
@@ -534,7 +565,7 @@ extern "C" int vqa_conv3x3_first_wgrad_bn(void* stream, int in_dtype, const void
                                           const float* invstd, const float* c1, const float* c2, float* part,
                                           float* dw, int G, int B, int IH, int IW, int OH, int OW, int pad, int R,
                                           int CW, int flip) {
-    if (!g || !scale || !shift || !mean || !invstd || !c1 || !c2) return VQA_ERR_ARG;
+    if (!g || !scale || !shift || (dw && (!mean || !invstd || !c1 || !c2))) return VQA_ERR_ARG;
     FirstArgs a{images, nullptr, static_cast<bf16*>(const_cast<void*>(y)), nullptr, part};
     a.wscale = nullptr;
     a.relu = 0;
@@ -543,4 +574,14 @@ extern "C" int vqa_conv3x3_first_wgrad_bn(void* stream, int in_dtype, const void
     a.g = static_cast<const bf16*>(g);
     a.bn_scale = scale; a.bn_shift = shift; a.bn_mean = mean; a.bn_invstd = invstd; a.bn_c1 = c1; a.bn_c2 = c2;
     return first_wgrad_launch(stream, in_dtype, a, part, dw, G, B, IH, IW, OH, OW, pad, R, CW, true);
+}
+
+extern "C" int vqa_conv3x3_first_wgrad_bn_reduce(void* stream, const float* part, int G, const float* scale,
+                                                 const float* mean, const float* invstd, const float* c1,
+                                                 const float* c2, float* dw) {
+    if (!part || G < 1 || !scale || !mean || !invstd || !c1 || !c2 || !dw) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(first_wgrad_reduce_bn, dim3(16), dim3(1024), 0, static_cast<hipStream_t>(stream), part, dw, G,
+                       scale, mean, invstd, c1, c2);
+    CHECK_LAUNCH();
+    return VQA_OK;
 }

@@ -658,7 +658,8 @@ BWD_SLICE_MIN_MB = float(os.environ.get('VQA_BWD_SLICE_MIN_MB', '300'))
 # BatchNorm 1's scale and shift; c1 and c2, which need every slice, enter when the slabs are combined).  Off: measured
 # on one box, 150-step runs: 3.953 / 3.961 / 3.957 against 3.960 / 3.955 / 3.961 ms/step with the default two slices
 # (a 128-image slice's traffic, 620 MB, is 2.4 x the Infinity Cache: little of d1 and y1 is still there), and SLOWER
-# with four (3.999 against 3.975-3.986; eight: 4.12): what the cache returns, the smaller launches take.
+# with four (3.999 against 3.975-3.986; eight: 4.12): what the cache returns, the smaller launches take.  (The slices'
+# launches on the weight-gradient stream instead of the chain: 4.000 against 3.951-3.956.)
 FIRST_WGRAD_SLICED = os.environ.get('VQA_FIRST_WGRAD_SLICED', '0') != '0'
 WGRAD_RESERVE = int(os.environ.get('VQA_WGRAD_RESERVE', '0'))
 # the deep weight gradient's four-output-fragment form (read by the library from the same variable; measured slower:

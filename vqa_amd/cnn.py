@@ -336,7 +336,7 @@ def first_fwd(images, w, bias, pad, want_stats, wscale=None, relu=False, mirror=
 def first_wgrad_rows(B, OH, OW):
     """Partial slabs ([3][16][32] f32 each) the fused first-layer weight gradient leaves for B images."""
     R, CW = pick_first_tile(OH, OW, 384)
-    return min(B * (-(-OH // R)) * (-(-OW // CW)), 256 * (4 - FIRST_RESERVE))
+    return min(B * (-(-OH // R)) * (-(-OW // CW)), 256 * (4 - FIRST_WGRAD_RESERVE))
 
 
 def first_wgrad(images, dy, pad, out=None, mirror=False, bn=None, part_out=None):
@@ -349,7 +349,8 @@ def first_wgrad(images, dy, pad, out=None, mirror=False, bn=None, part_out=None)
     R, CW = pick_first_tile(OH, OW, 384)                      # (wide tiles: long runs of dy; 0.155 -> 0.139 ms)
     tiles = B * (-(-OH // R)) * (-(-OW // CW))
     # persistent workgroups: what is resident per CU (84 registers -> 5 waves per SIMD; the fused kernel: 124 -> 4)
-    G = min(tiles, 256 * ((4 if bn is not None else 5) - FIRST_RESERVE))
+    # less FIRST_WGRAD_RESERVE
+    G = min(tiles, 256 * ((4 if bn is not None else 5) - FIRST_WGRAD_RESERVE))
     if part_out is not None:
         assert tuple(part_out.shape) == (G, 3, 16, 32) and part_out.is_contiguous() and len(bn) == 3
         tag = lambda: dict(kind='first_wgrad', shape=f'{OH}x{OW} 3->16', flops=2.0 * B * OH * OW * 27 * 16,
@@ -670,7 +671,14 @@ WGRAD_COF4 = os.environ.get('VQA_WGRAD_COF4', '0') != '0'
 # the slab sum of the layer above while the main stream had nothing left to do; on the main stream it starts at once
 # and those two run beside it: 4.180 -> 4.120 ms/step (5 alternations of 60 steps).  VQA_FIRST_WGRAD_MAIN=0: as before.
 FIRST_WGRAD_MAIN = os.environ.get('VQA_FIRST_WGRAD_MAIN', '1') != '0'
-FIRST_RESERVE = int(os.environ.get('VQA_FIRST_RESERVE', '0'))
+# Workgroup slots per CU that the first layer's persistent kernels leave to the other streams' kernels (the question
+# encoder's beside the forward kernel, the last weight-gradient slab sums beside the weight gradient).  Alone the
+# forward kernel is 3 % slower with four workgroups per CU than with five (147 against 143 us; three: 166); the step
+# gains 0.6 %: 3.921 / 3.923 / 3.922 against 3.950 / 3.941 / 3.950 ms (150-step runs alternated on one box; forward
+# only 3.940, two slots 3.927, three 3.966).  Round 2 had measured the same knob as neutral - before the trainer's
+# stream had priority and the question encoder ran from one call.
+FIRST_RESERVE = int(os.environ.get('VQA_FIRST_RESERVE', '1'))
+FIRST_WGRAD_RESERVE = int(os.environ.get('VQA_FIRST_WGRAD_RESERVE', str(FIRST_RESERVE)))
 # The deep layers' weight gradients (MFMA-bound, like the deep data gradients that run at the same time) are held back
 # and released onto the weight-gradient stream when the backward's main chain reaches the HBM-bound shallow blocks:
 # layers >= WGRAD_HOLD_FROM are issued after the main-stream launches of layer WGRAD_RELEASE_AT (0 / -1 = no holding).
@@ -707,7 +715,7 @@ def _wgrad_stream(dev):
 def _knobs():
     """Everything in this module the recorded launch sequence depends on (part of every plan key)."""
     return (WGRAD_STREAM, FUSE_BN_FWD, FUSE_BN_BWD, FUSE_FIRST_BN, FUSE_POOL_BWD, DEFER_WGRAD_REDUCE, BWD_SLICES,
-            BWD_SLICE_MIN_MB, WGRAD_RESERVE, FIRST_WGRAD_MAIN, FIRST_RESERVE, WGRAD_HOLD_FROM, WGRAD_RELEASE_AT,
+            BWD_SLICE_MIN_MB, WGRAD_RESERVE, FIRST_WGRAD_MAIN, FIRST_RESERVE, FIRST_WGRAD_RESERVE, WGRAD_HOLD_FROM, WGRAD_RELEASE_AT,
             FUSE_DGRAD_WGRAD,
             WGRAD_COF4, WGRAD_PAIR, FIRST_WGRAD_SLICED)
 

@@ -1,6 +1,6 @@
 """How much slack does the question encoder's stream have?  Events at the end of the recurrence's forward (question
 stream) and of the CNN's forward (trainer's stream), and at the end of the BPTT and of the CNN's backward, over steady
-steps.   python scripts/side_slack.py"""
+steps.   python scripts/side_slack.py [image tokens hidden batch]"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,15 +10,16 @@ from vqa_amd import synth
 from vqa_amd.optim import Trainer
 
 dev = torch.device('cuda', 0)
+IMG, TOK, HID, BATCH = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (224, 14, 1024, 256)))
 with tempfile.TemporaryDirectory() as tmp:
     qpath, lpath = bench.make_fixture(tmp, 10000, 3129)
     torch.manual_seed(42)
-    model = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': 1024, 'n_layers': 1,
+    model = vqa_model.VQA({'word_embd_dim': 300, 'question_hidden_dim': HID, 'n_layers': 1,
                            'train_question_path': qpath}, lpath, 256, 2, 0.0, 'max', 'relu')
 model = model.to(dev).train()
 tr = Trainer(model)
-batch = (synth.images(1234, 256, 224).to(dev), synth.questions(1234, 256, 14, 10000).to(dev),
-         synth.targets(1234, 256, 3129).to(dev))
+batch = (synth.images(1234, BATCH, IMG).to(dev), synth.questions(1234, BATCH, TOK, 10000).to(dev),
+         synth.targets(1234, BATCH, 3129).to(dev))
 marks = []
 gf, cf = model.gru.forward, model.cnn.forward
 

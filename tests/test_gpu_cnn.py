@@ -697,3 +697,45 @@ def test_paired_and_unpaired_tiles_store_the_same_bits(prec, cin, cout, H, W):
         d51 = (C.conv_wgrad(x[:5].contiguous(), dy[:5].contiguous(), cin, 0, in_coeffs=ic) +
                C.conv_wgrad(x[5:].contiguous(), dy[5:].contiguous(), cin, 0, in_coeffs=ic))
         assert float((d6 - d51).abs().max()) <= 2e-6 * float(d51.abs().max()) * (6 * H * W) ** 0.5
+
+
+@pytest.mark.parametrize('B,H,W,cin,cout', [(2, 34, 50, 16, 16), (3, 18, 18, 32, 32), (1, 66, 34, 16, 32), (2, 226, 226, 16, 16)])
+def test_conv_relu_maxpool_epilogue(B, H, W, cin, cout):
+    """vqa_conv3x3_fwd with relu = 3 (inference: conv + folded BatchNorm + ReLU + the 2x2 max pool from one kernel, the
+    full-resolution activation never written) against conv -> ReLU -> max_pool2d on the CPU (small integers: exact) and,
+    on random data, bit for bit against the two-kernel path relu = 1 -> vqa_bn_act_pool_fwd."""
+    from vqa_amd import cnn as C
+    torch.manual_seed(B * H + W + cin)
+    for exact in (True, False):
+        if exact:
+            x, w, bias = _ints((B, cin, H, W), -2, 3), _ints((cout, cin, 3, 3), -2, 3), _ints((cout,), -3, 4)
+        else:
+            x, w, bias = torch.randn(B, cin, H, W), torch.randn(cout, cin, 3, 3) * 0.1, torch.randn(cout) * 0.1
+        xd = _nhwc(x, torch.bfloat16)
+        assert C.conv_pool_ok(xd, 0)
+        wp = C.pack_weights(w.cuda(), cin, torch.bfloat16, dgrad=False)
+        got, _ = C.conv_fwd(xd, wp, bias.cuda(), cout, 0, False, relu=True, pool=True)
+        y, _ = C.conv_fwd(xd, wp, bias.cuda(), cout, 0, False, relu=True)
+        one, zero = torch.ones(cout, device='cuda'), torch.zeros(cout, device='cuda')
+        two = C.bn_act_pool(y, one, zero, 1)
+        assert got.shape == two.shape and torch.equal(got, two)
+        if exact:
+            ref = F.max_pool2d(F.relu(F.conv2d(x, w, bias)), 2, 2)
+            assert torch.equal(got.float().cpu().permute(0, 3, 1, 2), ref.bfloat16().float())
+
+
+def test_eval_forward_with_pooled_epilogue_is_bit_identical(monkeypatch):
+    """cnn.EVAL_FUSE_POOL (default): the inference pass of the encoder with blocks 1 and 2 pooling in their second
+    conv's epilogue against the same pass with the pool-only kernels."""
+    from vqa_amd import cnn as M, synth
+    sd = {k[4:]: v for k, v in synth.state_dict(42, 64, 50, 30).items() if k.startswith('cnn.')}
+    img = synth.images(5, 4, 224).cuda()
+    outs = []
+    for fuse in (True, False):
+        monkeypatch.setattr(M, 'EVAL_FUSE_POOL', fuse)
+        m = M.CNN(2, 'max', precision='bf16')
+        m.load_state_dict(sd)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            outs.append(m(img))
+    assert torch.equal(outs[0], outs[1])

@@ -100,9 +100,21 @@ def _conv_tag(kind, B, OH, OW, cin_real, cout_real, x, y_elems_bytes, w_bytes, k
     return tag
 
 
+def conv_pool_ok(x, pad):
+    """vqa_conv3x3_fwd can apply ReLU AND the 2x2 max pool in its epilogue for this input (inference): the single-chunk
+    bf16 kernel, an even output map, 16-column tiles with an even row count."""
+    B, IH, IW, cin = x.shape
+    OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
+    if not (EVAL_FUSE_POOL and x.dtype == torch.bfloat16 and cin in (16, 32) and OH % 2 == 0 and OW % 2 == 0):
+        return False
+    R, CW = pick_tile(OH, OW)
+    return CW == 16 and R % 2 == 0
+
+
 def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', relu=False, in_coeffs=None, bst=None,
-             out=None, stats_out=None):
+             out=None, stats_out=None, pool=False):
     """x NHWC [B,IH,IW,Cin] -> y [B,OH,OW,Cout] (+ partial BN statistics rows).
+    pool (with relu, conv_pool_ok): -> [B,OH/2,OW/2,Cout], the 2x2 max pool of relu(y) from the same kernel.
     in_coeffs = (scale, shift): x is the previous conv's RAW output and the kernel applies that layer's BatchNorm +
     ReLU while it stages its input tile (pad must be 0).
     bst = (y_below, coef [4,cout]): a data-gradient call whose output is the gradient w.r.t. the BatchNorm + ReLU output
@@ -110,6 +122,15 @@ def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', rel
     B, IH, IW, cin = x.shape
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
     R, CW = pick_tile(OH, OW)
+    if pool:
+        assert relu and not want_stats and in_coeffs is None and bst is None and out is None and conv_pool_ok(x, pad)
+        y = P.empty((B, OH // 2, OW // 2, cout), x.dtype, x.device)
+        G = _plan(L.dt(x), B, IH, IW, cin, OH, OW, cout, pad, R, CW, 4)
+        tag = lambda: _conv_tag(kind, B, OH, OW, cin if cin_real is None else cin_real, cout, x,
+                                y.numel() * y.element_size(), wpk.numel() * wpk.element_size(), kernel='conv3x3_igemm_p')
+        L.call('vqa_conv3x3_fwd', L.dt(x), x, wpk, y, bias, None, B, IH, IW, cin, OH, OW, cout, pad, R, CW, G, 3,
+               None, None, None, None, tag=tag)
+        return y, None
     y = P.empty((B, OH, OW, cout), x.dtype, x.device) if out is None else out
     G = _plan(L.dt(x), B, IH, IW, cin, OH, OW, cout, pad, R, CW, 1 if in_coeffs is not None else (2 if bst else 0))
     stats = None
@@ -605,6 +626,11 @@ def _eval_forward(x, first, params, buffers, padding, pool_mode, dtype):
         bf = coef[li, 2, :c]
         if first and li == 0:
             y, _ = first_fwd(x, w, bf, pad, False, wscale=coef[0, 0], relu=True)
+        elif li % 2 == 1 and pool_mode == 1 and conv_pool_ok(x, pad):
+            # (blocks 1 and 2 at 224 x 224: the full-resolution activation - 1.6 and 0.8 GB at B = 1024 - is never
+            # written; same bits as conv -> pool)
+            x, _ = conv_fwd(x, slabs[li], bf, c, pad, False, cin_real=w.shape[1], relu=True, pool=True)
+            continue
         else:
             y, _ = conv_fwd(x, slabs[li], bf, c, pad, False, cin_real=w.shape[1], relu=True)
         x = bn_act_pool(y, one, zero, pool_mode) if li % 2 == 1 else y       # relu(y) >= 0: pool-only pass
@@ -633,6 +659,9 @@ FUSE_BN_FWD = os.environ.get('VQA_FUSE_BN_FWD', '1') != '0'
 # traffic less); in the multi-chunk kernel the extra reads cost more than the pass (58x58x64: +0.10 ms for 0.046).
 FUSE_BN_BWD = int(os.environ.get('VQA_FUSE_BN_BWD', '32'))      # largest channel count it is applied to; 0 = never
 FUSE_FIRST_BN = os.environ.get('VQA_FUSE_FIRST_BN', '1') != '0'
+# Inference: ReLU and the 2x2 max pool in the epilogue of the pooled blocks' second conv where that conv is the
+# single-chunk kernel (vqa_conv3x3_fwd, relu = 3).  VQA_EVAL_FUSE_POOL=0: conv -> pool-only pass (same bits).
+EVAL_FUSE_POOL = os.environ.get('VQA_EVAL_FUSE_POOL', '1') != '0'
 # The same for a MAX-POOLED block below: its forward pool pass also stores ysel, the raw conv output at the position each
 # window selects (pooled resolution), and the data gradient above forms the BatchNorm-backward sums from (d, ysel) - the
 # reduce pass over the full-resolution y (4x the bytes) never runs.  Largest channel count of the pooled layer it is

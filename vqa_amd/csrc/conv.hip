@@ -32,7 +32,9 @@ struct ConvArgs {
     int B, IH, IW, Cin, OH, OW, Cout, pad;
     int R, CW, tiles_x, tiles_y;
     float inv_cw, inv_pw, inv_tx, inv_tiles;
-    int relu;           // epilogue: y = max(conv + bias, 0)  (eval mode with the BatchNorm folded into w / bias)
+    int relu;           // epilogue: bit 0: y = max(conv + bias, 0)  (eval mode with the BatchNorm folded into w / bias);
+                        // bit 1 (with bit 0; single-chunk bf16 kernel, 16-column tiles with an even row count on an
+                        // even map): the 2x2 max pool behind it as well - y is then [B][OH/2][OW/2][Cout]
     // XF kernels: x is the RAW output of the previous conv and the input really is relu(in_scale * x + in_shift) - the
     // previous layer's BatchNorm + ReLU, applied per 16-byte vector on the way into LDS ([Cin] each).  Only for
     // pad == 0 (every conv that follows an un-pooled block, cnn.py:24,28,32,36,40): no zero padding to preserve.
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv3x3_igemm_til
             }
         }
     } else {
-        switch ((a.relu ? 1 : 0) | (a.stats ? 2 : 0)) {
+        switch (((a.relu & 1) ? 1 : 0) | (a.stats ? 2 : 0)) {
             case 0: finish(std::integral_constant<int, 0>{}); break;
             case 1: finish(std::integral_constant<int, 1>{}); break;
             case 2: finish(std::integral_constant<int, 2>{}); break;
@@ -479,8 +481,9 @@ template <typename T, int CK, int NBF, int VAR>
 #ifndef VQA_DW_WAVES
 #define VQA_DW_WAVES 3
 #endif
-__global__ __launch_bounds__(256, (VAR >= 2 && NBF == 2) ? VQA_BST_WAVES : ((VAR == 3 && NBF == 1) ? VQA_DW_WAVES : 1)) void conv3x3_igemm_p(ConvArgs a) {
-    constexpr bool XF = VAR == 1, BST = VAR >= 2, WG = VAR == 3;
+__global__ __launch_bounds__(256, ((VAR == 2 || VAR == 3) && NBF == 2) ? VQA_BST_WAVES : ((VAR == 3 && NBF == 1) ? VQA_DW_WAVES : 1)) void conv3x3_igemm_p(ConvArgs a) {
+    constexpr bool XF = VAR == 1, BST = VAR == 2 || VAR == 3, WG = VAR == 3, POOL = VAR == 4;
+    static_assert(!POOL || sizeof(T) == 2, "pooled epilogue: bf16");
     static_assert(!WG || (sizeof(T) == 2 && ((CK == 16 && NBF == 1) || (CK == 32 && NBF == 2))), "weight-gradient forms");
     constexpr bool WG_PSPLIT = WG && CK == 16;                  // waves split the pixels (else: the tiles)
     constexpr int XSTR = NBF == 1 ? 32 : NBF * 32 + 32;         // LDS bytes per x pixel (32 * odd: dy_stride)
@@ -725,8 +728,44 @@ __global__ __launch_bounds__(256, (VAR >= 2 && NBF == 2) ? VQA_BST_WAVES : ((VAR
                     }
                 }
             }
+        } else if constexpr (POOL) {
+            // ReLU + 2x2 max pool (inference, BatchNorm folded): with 16-column tiles fragment f of this wave IS tile row
+            // 4 wave + f and lane r its column, so a window is fragments (2 f2, 2 f2 + 1) x lanes (r, r ^ 1).  The
+            // values are rounded to bf16 first - what the separate pool pass read - and compared as signed 16-bit
+            // integers (they are >= 0; a -0 loses to +0): the same bits as conv -> pool, a quarter of the stores.
+            typedef short s16x2 __attribute__((ext_vector_type(2)));
+            auto pmax = [](unsigned u, unsigned v) {
+                return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, u),
+                                                                              __builtin_bit_cast(s16x2, v)));
+            };
+            const int PHh = a.OH >> 1, PWh = a.OW >> 1;
+            const unsigned pbytes = (unsigned)a.B * PHh * PWh * a.Cout * (unsigned)sizeof(T);
+            const __amdgpu_buffer_rsrc_t pbuf = buffer_of(a.y, pbytes);
+            // (tile origins are even: R is, and CW = 16)
+            const unsigned pt = ((unsigned)((cb * PHh + (coy0 >> 1)) * PWh + (cox0 >> 1)) * a.Cout + co0 + q * 4) *
+                                (unsigned)sizeof(T);
+#pragma unroll
+            for (int n = 0; n < NBF; ++n) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(biasl + n * 16 + q * 4);
+#pragma unroll
+                for (int f2 = 0; f2 < 2; ++f2) {
+                    const Packed4<T> t0 = epilogue4<T, true, false>(acc[2 * f2][n], bv, 1.f, s1[n], s2[n]);
+                    const Packed4<T> t1 = epilogue4<T, true, false>(acc[2 * f2 + 1][n], bv, 1.f, s1[n], s2[n]);
+                    unsigned lo = pmax(t0.lo, t1.lo), hi = pmax(t0.hi, t1.hi);
+                    // the window's other column: lane r ^ 1 (DPP quad_perm [1, 0, 3, 2])
+                    lo = pmax(lo, (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, true));
+                    hi = pmax(hi, (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, true));
+                    const int pr = frc[2 * f2] >> 16, pr1 = frc[2 * f2 + 1] >> 16, pc = frc[2 * f2] & 0xFFFF;
+                    const bool ok = (r & 1) == 0 && coy0 + pr1 < a.OH && cox0 + pc + 1 < a.OW;
+                    const unsigned off = pt + (unsigned)(__mul24(__mul24(pr >> 1, PWh) + (pc >> 1), a.Cout) + n * 16) *
+                                              (unsigned)sizeof(T);
+                    Packed4<T> o;
+                    o.lo = lo; o.hi = hi;
+                    buffer_store_packed4<T>(pbuf, ok ? off : pbytes, o);
+                }
+            }
         } else {
-            switch ((a.relu ? 1 : 0) | (a.stats ? 2 : 0)) {
+            switch (((a.relu & 1) ? 1 : 0) | (a.stats ? 2 : 0)) {
                 case 0: finish(std::integral_constant<int, 0>{}); break;
                 case 1: finish(std::integral_constant<int, 1>{}); break;
                 case 2: finish(std::integral_constant<int, 2>{}); break;
@@ -809,6 +848,10 @@ int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
     const bool persistent = a.Cin == CK;
     const int var = a.in_scale ? 1 : (a.bn_y ? (a.wpart ? 3 : 2) : 0);
     auto kp = var == 1 ? conv3x3_igemm_p<T, CK, NBF, 1> : (var >= 2 ? conv3x3_igemm_p<T, CK, NBF, 2> : conv3x3_igemm_p<T, CK, NBF, 0>);
+    if (a.relu & 2) {                                           // (conv_fwd_entry: bf16, single chunk, plain variant)
+        if constexpr (sizeof(T) == 2) kp = conv3x3_igemm_p<T, CK, NBF, 4>;
+        else return plan_only ? -1 : VQA_ERR_ARG;
+    }
     if (var == 3) {
         // the forms the kernel has (bf16, all of the conv's channels in one workgroup), + the x tile; the <16, 1>
         // form's combine buffer of the last tile is the floor
@@ -1327,6 +1370,11 @@ static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* w
     if (OH != IH + 2 * pad - 2 || OW != IW + 2 * pad - 2 || R < 1 || CW < 1 || R * CW > 256 ||
         (R + 2) * (CW + 2) > 384 || B < 1)
         return bad;
+    // ReLU + 2x2 max pool in the epilogue (relu == 3): the single-chunk bf16 kernel on 16-column tiles, whole windows
+    if (relu & ~3) return bad;
+    if ((relu & 2) && (!(relu & 1) || dtype != VQA_BF16 || (Cin != 16 && Cin != 32) || CW != 16 || (R & 1) || (OH & 1) ||
+                       (OW & 1) || stats || in_scale || bn_y))
+        return bad;
     // the kernels address x and y through 32-bit byte offsets (buffer resources)
     const int esz_ = dtype == VQA_BF16 ? 2 : 4;
     if ((double)B * IH * IW * Cin * esz_ >= 4294967040.0 || (double)B * OH * OW * Cout * esz_ >= 4294967040.0) return bad;
@@ -1374,7 +1422,10 @@ extern "C" int vqa_conv3x3_plan(int dtype, int B, int IH, int IW, int Cin, int O
     static const float dummy = 0.f;
     const float* xf = variant == 1 ? &dummy : nullptr;
     const float* bst = variant >= 2 ? &dummy : nullptr;
-    if (variant < 0 || variant > 3) return -1;
+    if (variant < 0 || variant > 4) return -1;       // (4: the pooled ReLU epilogue, vqa_conv3x3_fwd with relu = 3)
+    if (variant == 4)
+        return conv_fwd_entry(nullptr, dtype, nullptr, nullptr, nullptr, nullptr, nullptr, B, IH, IW, Cin, OH, OW, Cout,
+                              pad, R, CW, 0, true, 3);
     return conv_fwd_entry(nullptr, dtype, nullptr, nullptr, nullptr, nullptr, nullptr, B, IH, IW, Cin, OH, OW, Cout,
                           pad, R, CW, 0, true, 0, xf, xf, bst, bst, variant == 3 ? const_cast<float*>(&dummy) : nullptr);
 }

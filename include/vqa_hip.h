@@ -66,9 +66,10 @@ int vqa_conv_pack_all(void* stream, int dtype, int n, const void* const* w, void
  * what vqa_bn_bwd(apply = 0, pool = 0) would produce from (bn_y, d) in a pass of its own; feed vqa_bn_bwd_finalize.
  * relu: 0 = none, 1 = y = max(conv + bias, 0) (inference with the BatchNorm folded into w / bias: cnn.py:23-24 as one
  * kernel), 3 = that AND the nn.MaxPool2d(2, 2) behind it (cnn.py:27, :31): y is then [B][OH/2][OW/2][Cout] and the
- * full-resolution activation is never written.  relu = 3 needs the single-chunk bf16 kernel (Cin 16 or 32), OH and OW
- * even, CW == 16 and R even, no stats / in_scale / bn_y; G from vqa_conv3x3_plan(variant 4).  Same bits as relu = 1
- * followed by vqa_bn_act_pool_fwd with unit scale, zero shift and pool = 1. */
+ * full-resolution activation is never written.  relu = 3 needs bf16, OH, OW, R and CW even (CW == 16 for the
+ * single-chunk kernel, Cin 16 or 32), no stats / in_scale / bn_y, and turns the two-images-per-tile form off; G from
+ * vqa_conv3x3_plan(variant 4).  Same bits as relu = 1 followed by vqa_bn_act_pool_fwd with unit scale, zero shift and
+ * pool = 1. */
 int vqa_conv3x3_fwd(void* stream, int dtype, const void* x, const void* wpacked, void* y, const float* bias,
                     float* stats, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int pad, int R, int CW,
                     int G, int relu /* 1: y = max(conv + bias, 0) - eval mode with the BatchNorm folded into w, bias */,

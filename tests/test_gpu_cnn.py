@@ -699,7 +699,8 @@ def test_paired_and_unpaired_tiles_store_the_same_bits(prec, cin, cout, H, W):
         assert float((d6 - d51).abs().max()) <= 2e-6 * float(d51.abs().max()) * (6 * H * W) ** 0.5
 
 
-@pytest.mark.parametrize('B,H,W,cin,cout', [(2, 34, 50, 16, 16), (3, 18, 18, 32, 32), (1, 66, 34, 16, 32), (2, 226, 226, 16, 16)])
+@pytest.mark.parametrize('B,H,W,cin,cout', [(2, 34, 50, 16, 16), (3, 18, 18, 32, 32), (1, 66, 34, 16, 32), (2, 226, 226, 16, 16),
+                                            (2, 58, 58, 64, 64), (3, 30, 30, 128, 128), (1, 30, 38, 64, 128), (2, 22, 38, 256, 64), (1, 14, 62, 96, 32)])
 def test_conv_relu_maxpool_epilogue(B, H, W, cin, cout):
     """vqa_conv3x3_fwd with relu = 3 (inference: conv + folded BatchNorm + ReLU + the 2x2 max pool from one kernel, the
     full-resolution activation never written) against conv -> ReLU -> max_pool2d on the CPU (small integers: exact) and,

@@ -101,14 +101,17 @@ def _conv_tag(kind, B, OH, OW, cin_real, cout_real, x, y_elems_bytes, w_bytes, k
 
 
 def conv_pool_ok(x, pad):
-    """vqa_conv3x3_fwd can apply ReLU AND the 2x2 max pool in its epilogue for this input (inference): the single-chunk
-    bf16 kernel, an even output map, 16-column tiles with an even row count."""
+    """vqa_conv3x3_fwd can apply ReLU AND the 2x2 max pool in its epilogue for this input (inference): bf16, an even
+    output map, even tiles (16 columns wide in the single-chunk kernel)."""
     B, IH, IW, cin = x.shape
     OH, OW = IH + 2 * pad - 2, IW + 2 * pad - 2
-    if not (EVAL_FUSE_POOL and x.dtype == torch.bfloat16 and cin in (16, 32) and OH % 2 == 0 and OW % 2 == 0):
+    if not (EVAL_FUSE_POOL and x.dtype == torch.bfloat16 and cin % 16 == 0 and OH % 2 == 0 and OW % 2 == 0):
         return False
     R, CW = pick_tile(OH, OW)
-    return CW == 16 and R % 2 == 0
+    if cin in (16, 32):                 # single-chunk kernel: a window = two fragments of a lane and its neighbour
+        return CW == 16 and R % 2 == 0
+    # multi-chunk kernel: any even tile; not the one-tile maps (they share a tile between two images instead)
+    return cin % 32 == 0 and R % 2 == 0 and CW % 2 == 0 and not (R >= OH and CW >= OW)
 
 
 def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', relu=False, in_coeffs=None, bst=None,
@@ -127,7 +130,8 @@ def conv_fwd(x, wpk, bias, cout, pad, want_stats, cin_real=None, kind='fwd', rel
         y = P.empty((B, OH // 2, OW // 2, cout), x.dtype, x.device)
         G = _plan(L.dt(x), B, IH, IW, cin, OH, OW, cout, pad, R, CW, 4)
         tag = lambda: _conv_tag(kind, B, OH, OW, cin if cin_real is None else cin_real, cout, x,
-                                y.numel() * y.element_size(), wpk.numel() * wpk.element_size(), kernel='conv3x3_igemm_p')
+                                y.numel() * y.element_size(), wpk.numel() * wpk.element_size(),
+                                kernel='conv3x3_igemm_p' if cin == _ck(cin, x.dtype) else 'conv3x3_igemm_tile')
         L.call('vqa_conv3x3_fwd', L.dt(x), x, wpk, y, bias, None, B, IH, IW, cin, OH, OW, cout, pad, R, CW, G, 3,
                None, None, None, None, tag=tag)
         return y, None
@@ -627,8 +631,8 @@ def _eval_forward(x, first, params, buffers, padding, pool_mode, dtype):
         if first and li == 0:
             y, _ = first_fwd(x, w, bf, pad, False, wscale=coef[0, 0], relu=True)
         elif li % 2 == 1 and pool_mode == 1 and conv_pool_ok(x, pad):
-            # (blocks 1 and 2 at 224 x 224: the full-resolution activation - 1.6 and 0.8 GB at B = 1024 - is never
-            # written; same bits as conv -> pool)
+            # (blocks 1 to 4 at 224 x 224: the full-resolution activation - 1.6, 0.8, 0.4 and 0.2 GB at B = 1024 - is
+            # never written; same bits as conv -> pool)
             x, _ = conv_fwd(x, slabs[li], bf, c, pad, False, cin_real=w.shape[1], relu=True, pool=True)
             continue
         else:

@@ -33,8 +33,8 @@ struct ConvArgs {
     int R, CW, tiles_x, tiles_y;
     float inv_cw, inv_pw, inv_tx, inv_tiles;
     int relu;           // epilogue: bit 0: y = max(conv + bias, 0)  (eval mode with the BatchNorm folded into w / bias);
-                        // bit 1 (with bit 0; single-chunk bf16 kernel, 16-column tiles with an even row count on an
-                        // even map): the 2x2 max pool behind it as well - y is then [B][OH/2][OW/2][Cout]
+                        // bit 1 (with bit 0; bf16, even tiles on an even map, 16 columns wide in the single-chunk
+                        // kernel): the 2x2 max pool behind it as well - y is then [B][OH/2][OW/2][Cout]
     // XF kernels: x is the RAW output of the previous conv and the input really is relu(in_scale * x + in_shift) - the
     // previous layer's BatchNorm + ReLU, applied per 16-byte vector on the way into LDS ([Cin] each).  Only for
     // pad == 0 (every conv that follows an un-pooled block, cnn.py:24,28,32,36,40): no zero padding to preserve.
@@ -90,9 +90,11 @@ __device__ unsigned long long g_stamps[16384][12];
 // ---------------------------------------------------------------------------------------------- igemm
 // One workgroup per (tile, image, channel block): the multi-chunk (Cin > CK) layers, which are MFMA-bound and
 // want their registers for the accumulators and the chunk prefetch rather than for persistent-loop state.
-template <typename T, int CK, int NBF, int VAR>   // VAR: 0 plain, 1 XF (input BatchNorm + ReLU), 2 BST (see ConvArgs)
+template <typename T, int CK, int NBF, int VAR>   // VAR: 0 plain, 1 XF (input BatchNorm + ReLU), 2 BST (see ConvArgs),
+                                                  // 3 POOL (inference: ReLU + 2x2 max pool in the epilogue, relu = 3)
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv3x3_igemm_tile(ConvArgs a) {   // (two waves per SIMD)
-    constexpr bool XF = VAR == 1, BST = VAR == 2;
+    constexpr bool XF = VAR == 1, BST = VAR == 2, POOL = VAR == 3;
+    static_assert(!POOL || sizeof(T) == 2, "pooled epilogue: bf16");
     using Cfg = ConvCfg<T, CK>;
     constexpr int VEC = Cfg::VEC, KC = Cfg::KC, KP = Cfg::KP, NS = Cfg::NS, PXB = Cfg::PXB, WROWB = Cfg::WROWB,
                   VPP = Cfg::VPP;
@@ -358,7 +360,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv3x3_igemm_til
                 if constexpr (MS && STATS) {
                     if (opix[f] < 0) o = Packed4<T>{};
                 }
-                store_packed4<T>(reinterpret_cast<T*>(ew + (f * 16 + r) * EROW) + n * 16 + q * 4, o);
+                // (POOL: rows in TILE order - fragment f of this wave is fragment 4 f + wave of the tile - for the
+                // windows that the pooled stores below read across the waves' fragments)
+                if constexpr (POOL)
+                    store_packed4<T>(reinterpret_cast<T*>(smem + ((f * 4 + wave) * 16 + r) * EROW) + n * 16 + q * 4, o);
+                else
+                    store_packed4<T>(reinterpret_cast<T*>(ew + (f * 16 + r) * EROW) + n * 16 + q * 4, o);
             }
         }
     };
@@ -390,6 +397,34 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv3x3_igemm_til
         }
     }
     STAMP(7);
+    if constexpr (POOL) {
+        // The tile (R x CW, both even, on an even map at an even origin: whole windows) sits in LDS as bf16 rows of NB
+        // channels; a thread takes one 16-byte channel vector of one window: four row reads, three packed signed
+        // 16-bit maxima per dword (the values are relu'd: >= 0), one store to the pooled map.  Same bits as the
+        // pool-only pass over the stored activation.
+        __syncthreads();
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        auto pmax = [](unsigned u, unsigned v) {
+            return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, u),
+                                                                          __builtin_bit_cast(s16x2, v)));
+        };
+        auto vmax = [&](const uint4& u, const uint4& v) {
+            return make_uint4(pmax(u.x, v.x), pmax(u.y, v.y), pmax(u.z, v.z), pmax(u.w, v.w));
+        };
+        const int PC = a.CW >> 1, PHh = a.OH >> 1, PWh = a.OW >> 1;
+        T* yp = y + ((long)(b * PHh + (oy0 >> 1)) * PWh + (ox0 >> 1)) * a.Cout + co0;
+        for (int idx = tid; idx < (a.R >> 1) * PC * VPR; idx += 256) {
+            const int pp = idx / VPR, c = idx - pp * VPR;
+            const int ppr = pp / PC, ppc = pp - ppr * PC;
+            const unsigned char* p0 = smem + (2 * ppr * a.CW + 2 * ppc) * EROW + c * 16;
+            const uint4 top = vmax(*reinterpret_cast<const uint4*>(p0), *reinterpret_cast<const uint4*>(p0 + EROW));
+            const uint4 bot = vmax(*reinterpret_cast<const uint4*>(p0 + a.CW * EROW),
+                                   *reinterpret_cast<const uint4*>(p0 + (a.CW + 1) * EROW));
+            if (oy0 + 2 * ppr + 1 < a.OH && ox0 + 2 * ppc + 1 < a.OW)
+                *reinterpret_cast<uint4*>(yp + ((long)ppr * PWh + ppc) * a.Cout + c * 8) = vmax(top, bot);
+        }
+        return;
+    }
     if (a.stats) {
         // [4 waves][NB][2] behind the transpose regions: the sums are ready before any global store is issued, so the
         // barrier below does not wait for stores
@@ -868,6 +903,9 @@ int launch_igemm(hipStream_t s, const ConvArgs& a, int G, bool plan_only) {
     if (lds > 160 * 1024) return plan_only ? -1 : VQA_ERR_ARG;
     auto kt = var == 1 ? conv3x3_igemm_tile<T, CK, NBF, 1>
                        : (var >= 2 ? conv3x3_igemm_tile<T, CK, NBF, 2> : conv3x3_igemm_tile<T, CK, NBF, 0>);
+    if constexpr (sizeof(T) == 2) {
+        if (a.relu & 2) kt = conv3x3_igemm_tile<T, CK, NBF, 3>;
+    }
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(persistent ? (const void*)kp : (const void*)kt,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1372,8 +1410,10 @@ static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* w
         return bad;
     // ReLU + 2x2 max pool in the epilogue (relu == 3): the single-chunk bf16 kernel on 16-column tiles, whole windows
     if (relu & ~3) return bad;
-    if ((relu & 2) && (!(relu & 1) || dtype != VQA_BF16 || (Cin != 16 && Cin != 32) || CW != 16 || (R & 1) || (OH & 1) ||
-                       (OW & 1) || stats || in_scale || bn_y))
+    // (single chunk, Cin 16 / 32: 16-column tiles - a window is two fragments of a lane and its neighbour; multi chunk:
+    // any even tile, the windows are read back from the epilogue's LDS transpose)
+    if ((relu & 2) && (!(relu & 1) || dtype != VQA_BF16 || (R & 1) || (CW & 1) || (OH & 1) || (OW & 1) || stats ||
+                       in_scale || bn_y || !((Cin == 16 || Cin == 32) ? CW == 16 : Cin % 32 == 0)))
         return bad;
     // the kernels address x and y through 32-bit byte offsets (buffer resources)
     const int esz_ = dtype == VQA_BF16 ? 2 : 4;
@@ -1384,7 +1424,7 @@ static int conv_fwd_entry(hipStream_t s, int dtype, const void* x, const void* w
     static const int pair_on = [] { const char* e = getenv("VQA_CONV_PAIR"); return e ? atoi(e) : 1; }();
     int seam = 0;
     const int ck_ = dtype == VQA_BF16 ? 32 : 16;
-    if (pair_on && pad == 0 && !bn_y && Cin > ck_ && R >= OH && CW >= OW && B % 2 == 0 && (2 * OH + 2) * CW <= 256 &&
+    if (pair_on && !(relu & 2) && pad == 0 && !bn_y && Cin > ck_ && R >= OH && CW >= OW && B % 2 == 0 && (2 * OH + 2) * CW <= 256 &&
         (2 * IH) * (CW + 2) <= 384) {
         seam = OH;
         B /= 2; IH *= 2; OH = 2 * OH + 2; R = OH;

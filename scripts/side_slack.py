@@ -1,6 +1,6 @@
 """How much slack does the question encoder's stream have?  Events at the end of the recurrence's forward (question
 stream) and of the CNN's forward (trainer's stream), and at the end of the BPTT and of the CNN's backward, over steady
-steps.   python scripts/side_slack.py [image tokens hidden batch]"""
+steps.   python scripts/side_slack.py [image tokens hidden batch [eval]]"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -47,14 +47,27 @@ def cnn_fwd(*a, **k):
 
 
 model.gru.forward, model.cnn.forward = gru_fwd, cnn_fwd
+EVAL = len(sys.argv) > 5 and sys.argv[5] == 'eval'
+if EVAL:
+    model.eval()
+
+
+def one_step():
+    if EVAL:
+        with torch.no_grad():
+            model(batch[0], batch[1])
+    else:
+        tr.step(*batch)
+
+
 with torch.cuda.stream(tr.stream):
     for _ in range(20):
-        tr.step(*batch)
+        one_step()
     torch.cuda.synchronize()
     marks.clear()
     t0 = ev()
     for _ in range(5):
-        tr.step(*batch)
+        one_step()
     t1 = ev()
     torch.cuda.synchronize()
 print(f'{t0.elapsed_time(t1) / 5:.3f} ms/step')
